@@ -1,0 +1,208 @@
+"""ctypes binding of libdptm.so (C ABI in include/dptm.h).
+
+There is no CPU fallback: if the shared library is missing or does not export the
+expected symbols, importing a scorer fails loudly with ``NativeLibraryError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .spec import DEFAULT_SPEC, ModelSpec
+
+_LIB_NAME = "libdptm.so"
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+DPTM_OK, DPTM_EINVAL, DPTM_EHIP, DPTM_ENOMEM = 0, -1, -2, -3
+PROF_NAMES = ("assemble", "branch21", "branch33", "branch51", "struct", "esm1", "esm2",
+              "trunk1", "trunk2", "head")
+
+EXPORTS = (
+    "dptm_weight_count", "dptm_create", "dptm_destroy", "dptm_score", "dptm_score_protein",
+    "dptm_score_device", "dptm_score_protein_device", "dptm_assemble_device", "dptm_sync",
+    "dptm_profile_begin", "dptm_profile_end", "dptm_chunk_sites", "dptm_last_error",
+)
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class DptmSpec(C.Structure):
+    _fields_ = [
+        ("n_windows", C.c_int32), ("window_sizes", C.c_int32 * 3), ("max_features", C.c_int32),
+        ("embed_dim", C.c_int32), ("num_heads", C.c_int32), ("ff_dim", C.c_int32),
+        ("esm_dim", C.c_int32), ("struct_feature_dim", C.c_int32), ("struct_units", C.c_int32),
+        ("esm_units1", C.c_int32), ("esm_units2", C.c_int32), ("trunk_units1", C.c_int32),
+        ("trunk_units2", C.c_int32), ("n_classes", C.c_int32),
+    ]
+
+    @classmethod
+    def from_spec(cls, spec: ModelSpec) -> "DptmSpec":
+        s = cls()
+        ws = list(spec.window_sizes)[:3] + [0] * (3 - min(3, len(spec.window_sizes)))
+        s.n_windows = len(spec.window_sizes)
+        s.window_sizes = (C.c_int32 * 3)(*ws)
+        s.max_features = spec.max_features
+        s.embed_dim = spec.embed_dim
+        s.num_heads = spec.num_heads
+        s.ff_dim = spec.ff_dim
+        s.esm_dim = spec.esm_dim
+        s.struct_feature_dim = spec.struct_feature_dim
+        s.struct_units = spec.struct_units
+        s.esm_units1 = spec.esm_units1
+        s.esm_units2 = spec.esm_units2
+        s.trunk_units1 = spec.trunk_units1
+        s.trunk_units2 = spec.trunk_units2
+        s.n_classes = spec.n_classes
+        return s
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load_library() -> C.CDLL:
+    """dlopen libdptm.so and declare its prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise NativeLibraryError(
+            f"{_LIB_PATH} is missing: build it with `make -C deepptmpred_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    try:
+        lib = C.CDLL(_LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the machine
+        raise NativeLibraryError(f"cannot load {_LIB_PATH}: {e}") from e
+    missing = [n for n in EXPORTS if not hasattr(lib, n)]
+    if missing:
+        raise NativeLibraryError(f"{_LIB_PATH} lacks symbols: {missing}")
+    vp, i64, u8p, f32p, i32p = C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p
+    lib.dptm_weight_count.restype = C.c_int64
+    lib.dptm_weight_count.argtypes = [C.POINTER(DptmSpec)]
+    lib.dptm_create.restype = C.c_int
+    lib.dptm_create.argtypes = [vp, C.c_size_t, C.POINTER(DptmSpec), C.c_int, C.POINTER(vp)]
+    lib.dptm_destroy.restype = None
+    lib.dptm_destroy.argtypes = [vp]
+    lib.dptm_score.restype = C.c_int
+    lib.dptm_score.argtypes = [vp, u8p, u8p, u8p, f32p, f32p, i64, f32p]
+    lib.dptm_score_protein.restype = C.c_int
+    lib.dptm_score_protein.argtypes = [vp, u8p, i64, f32p, i64, i32p, f32p, i64, f32p]
+    lib.dptm_score_device.restype = C.c_int
+    lib.dptm_score_device.argtypes = [vp, u8p, u8p, u8p, f32p, f32p, i64, f32p, vp]
+    lib.dptm_score_protein_device.restype = C.c_int
+    lib.dptm_score_protein_device.argtypes = [vp, u8p, i64, f32p, i64, i32p, f32p, i64, f32p, vp]
+    lib.dptm_assemble_device.restype = C.c_int
+    lib.dptm_assemble_device.argtypes = [vp, u8p, i64, i64, i32p, i64, u8p, u8p, u8p, i32p, vp]
+    lib.dptm_sync.restype = C.c_int
+    lib.dptm_sync.argtypes = [vp]
+    lib.dptm_profile_begin.restype = C.c_int
+    lib.dptm_profile_begin.argtypes = [vp]
+    lib.dptm_profile_end.restype = C.c_int
+    lib.dptm_profile_end.argtypes = [vp, C.c_void_p, C.c_void_p]
+    lib.dptm_chunk_sites.restype = C.c_int64
+    lib.dptm_chunk_sites.argtypes = [vp]
+    lib.dptm_last_error.restype = C.c_char_p
+    lib.dptm_last_error.argtypes = []
+    _lib = lib
+    return lib
+
+
+def _check(lib, rc: int, what: str) -> None:
+    if rc == DPTM_OK:
+        return
+    msg = (lib.dptm_last_error() or b"").decode("utf-8", "replace")
+    if rc == DPTM_EINVAL:
+        raise ValueError(f"{what}: {msg}")
+    if rc == DPTM_ENOMEM:
+        raise MemoryError(f"{what}: {msg}")
+    raise RuntimeError(f"{what}: {msg}")
+
+
+def _ptr(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)
+
+
+class Scorer:
+    """One ``dptm_handle``: a weight set resident on one GPU."""
+
+    def __init__(self, blob: np.ndarray, spec: ModelSpec = DEFAULT_SPEC, device: int = 0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.spec = spec
+        self.device = device
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        cs = DptmSpec.from_spec(spec)
+        rc = self._lib.dptm_create(_ptr(blob), blob.nbytes, C.byref(cs), device, C.byref(self._h))
+        _check(self._lib, rc, "dptm_create")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.dptm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def chunk_sites(self) -> int:
+        return int(self._lib.dptm_chunk_sites(self._h))
+
+    # ---- host-buffer calls (numpy in, numpy out)
+    def score(self, tok21, tok33, tok51, strct, esm) -> np.ndarray:
+        n = len(tok21)
+        out = np.empty((n, 2), dtype=np.float32)
+        rc = self._lib.dptm_score(self._h, _ptr(tok21), _ptr(tok33), _ptr(tok51), _ptr(strct),
+                                  _ptr(esm), n, _ptr(out))
+        _check(self._lib, rc, "dptm_score")
+        return out
+
+    def score_protein(self, codes, esm_table, positions, strct) -> np.ndarray:
+        n = len(positions)
+        out = np.empty((n, 2), dtype=np.float32)
+        rows = 0 if esm_table is None else len(esm_table)
+        tp = C.c_void_p(None) if esm_table is None or rows == 0 else _ptr(esm_table)
+        rc = self._lib.dptm_score_protein(self._h, _ptr(codes), len(codes), tp, rows,
+                                          _ptr(positions), _ptr(strct), n, _ptr(out))
+        _check(self._lib, rc, "dptm_score_protein")
+        return out
+
+    # ---- device-pointer calls (integers = device addresses, e.g. torch data_ptr())
+    def score_device(self, tok21, tok33, tok51, strct, esm, n, out, stream=0) -> None:
+        rc = self._lib.dptm_score_device(self._h, tok21, tok33, tok51, strct, esm, n, out,
+                                         C.c_void_p(stream or None))
+        _check(self._lib, rc, "dptm_score_device")
+
+    def score_protein_device(self, codes, L, esm_table, esm_rows, positions, strct, n, out,
+                             stream=0) -> None:
+        rc = self._lib.dptm_score_protein_device(self._h, codes, L, esm_table, esm_rows, positions,
+                                                 strct, n, out, C.c_void_p(stream or None))
+        _check(self._lib, rc, "dptm_score_protein_device")
+
+    def assemble_device(self, codes, L, esm_rows, positions, n, tok21, tok33, tok51, esm_row,
+                        stream=0) -> None:
+        rc = self._lib.dptm_assemble_device(self._h, codes, L, esm_rows, positions, n, tok21, tok33,
+                                            tok51, esm_row, C.c_void_p(stream or None))
+        _check(self._lib, rc, "dptm_assemble_device")
+
+    def sync(self) -> None:
+        _check(self._lib, self._lib.dptm_sync(self._h), "dptm_sync")
+
+    def profile_begin(self) -> None:
+        _check(self._lib, self._lib.dptm_profile_begin(self._h), "dptm_profile_begin")
+
+    def profile_end(self):
+        ms = np.zeros(len(PROF_NAMES), dtype=np.float32)
+        cnt = np.zeros(len(PROF_NAMES), dtype=np.int64)
+        _check(self._lib, self._lib.dptm_profile_end(self._h, _ptr(ms), _ptr(cnt)), "dptm_profile_end")
+        return {k: (float(m), int(c)) for k, m, c in zip(PROF_NAMES, ms, cnt)}

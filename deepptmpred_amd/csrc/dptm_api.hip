@@ -1,0 +1,608 @@
+// C ABI of libdptm.so (declared in include/dptm.h): weight packing, device memory,
+// chunked launch sequences and HIP-event profiling around the kernels of
+// dptm_kernels.hip.  Host code only; no kernel lives in this file.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dptm.h"
+#include "dptm_kernels.h"
+#include "dptm_layout.h"
+
+using namespace dptm;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(DPTM_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+constexpr double kBnEps = 1e-3;  // keras BatchNormalization default epsilon
+constexpr int64_t kChunkSites = 32768;
+
+// ---- host-side packing into the layouts of dptm_layout.h
+
+// W is a Keras kernel [K][N] (row-major).  dst gets n_pad/32 * K/8 * 64 float4.
+void pack_matrix(const float* W, int K, int N, int n_pad, float* dst) {
+    const int k8 = K / 8;
+    for (int t = 0; t < n_pad / 32; ++t)
+        for (int u = 0; u < k8; ++u)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int h = lane >> 5, j = lane & 31;
+                for (int e = 0; e < 4; ++e) {
+                    const int kk = 8 * u + 4 * h + e, nn = 32 * t + j;
+                    dst[(((size_t)t * k8 + u) * 64 + lane) * 4 + e] =
+                        nn < N ? W[(size_t)kk * N + nn] : 0.0f;
+                }
+            }
+}
+
+// v has F features; dst gets f_pad/4 floats grouped [half][group][4].
+void pack_vector(const float* v, int F, int f_pad, float* dst) {
+    const int g8 = f_pad / 8;
+    for (int h = 0; h < 2; ++h)
+        for (int u = 0; u < g8; ++u)
+            for (int e = 0; e < 4; ++e) {
+                const int f = 8 * u + 4 * h + e;
+                dst[((size_t)h * g8 + u) * 4 + e] = f < F ? v[f] : 0.0f;
+            }
+}
+
+// BatchNorm at inference as y = x*scale + shift (gamma, beta, mean, var consecutive)
+void bn_affine(const float* g, const float* b, const float* mu, const float* var, int n,
+               std::vector<float>& scale, std::vector<float>& shift) {
+    scale.resize(n);
+    shift.resize(n);
+    for (int i = 0; i < n; ++i) {
+        const double s = (double)g[i] / std::sqrt((double)var[i] + kBnEps);
+        scale[i] = (float)s;
+        shift[i] = (float)((double)b[i] - (double)mu[i] * s);
+    }
+}
+
+struct Reader {
+    const float* p;
+    const float* take(size_t n) {
+        const float* r = p;
+        p += n;
+        return r;
+    }
+};
+
+struct DenseLayer {
+    int k = 0, n = 0, n_pad = 0;
+    float* d_w = nullptr;
+    float* d_bias = nullptr;
+    float* d_scale = nullptr;
+    float* d_shift = nullptr;
+};
+
+struct ProfRec {
+    int cls;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct dptm_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    float* d_branch[3] = {nullptr, nullptr, nullptr};
+    DenseLayer strct, esm1, esm2, t1, t2, head;
+    // per-chunk workspace
+    float* d_concat = nullptr;
+    float* d_h1 = nullptr;
+    float* d_t1 = nullptr;
+    float* d_t2 = nullptr;
+    float* d_zero_row = nullptr;
+    // per-chunk staging for assembled windows
+    uint8_t* d_tok[3] = {nullptr, nullptr, nullptr};
+    int32_t* d_esm_row = nullptr;
+    // staging for the host-buffer entry points (allocated on first use)
+    float* s_strct = nullptr;
+    float* s_esm = nullptr;
+    float* s_out = nullptr;
+    uint8_t* s_tok[3] = {nullptr, nullptr, nullptr};
+    uint8_t* s_codes = nullptr;
+    int64_t s_codes_cap = 0;
+    float* s_table = nullptr;
+    int64_t s_table_cap = 0;
+    int32_t* s_pos = nullptr;
+    bool prof_armed = false;
+    std::vector<ProfRec> prof;
+};
+
+namespace {
+
+const int kWin[3] = {21, 33, 51};
+
+bool spec_supported(const dptm_spec* s) {
+    return s && s->n_windows == 3 && s->window_sizes[0] == 21 && s->window_sizes[1] == 33 &&
+           s->window_sizes[2] == 51 && s->max_features == kCodes && s->embed_dim == kD &&
+           s->num_heads == kHeads && s->ff_dim == kFF && s->esm_dim == kEsm &&
+           s->struct_feature_dim == kStruct && s->struct_units == kStructUnits &&
+           s->esm_units1 == kEsm1 && s->esm_units2 == kEsm2 && s->trunk_units1 == kT1 &&
+           s->trunk_units2 == kT2 && s->n_classes == 2;
+}
+
+int64_t weight_count() {
+    int64_t per_branch_fixed = kCodes * kD + (kD * kD + kD) + 2 * (3 * kD * kD + kD + 4 * kD) +
+                               2 * (4 * (kD * kD + kD) + kD * kFF + kFF + kFF * kD + kD + 4 * kD) +
+                               kD + 1;
+    int64_t total = 3 * per_branch_fixed + (21 + 33 + 51) * kD;
+    total += kStruct * kStructUnits + kStructUnits + 4 * kStructUnits;
+    total += (int64_t)kEsm * kEsm1 + kEsm1 + 4 * kEsm1;
+    total += kEsm1 * kEsm2 + kEsm2;
+    total += kConcat * kT1 + kT1 + 4 * kT1;
+    total += kT1 * kT2 + kT2 + 4 * kT2;
+    total += kT2 * 2 + 2;
+    return total;
+}
+
+int upload(const std::vector<float>& v, float** d) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(d), v.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(*d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return DPTM_OK;
+}
+
+// Packs one sequence branch (tensor order of spec.py:tensor_table) into the buffer
+// layout of dptm_layout.h.
+void pack_branch(Reader& rd, int W, std::vector<float>& buf) {
+    buf.assign((size_t)kBranchF4 * 4, 0.0f);
+    float* B = buf.data();
+    auto f4 = [&](int off) { return B + (size_t)off * 4; };
+    std::memcpy(f4(kOffEmb), rd.take(kCodes * kD), sizeof(float) * kCodes * kD);
+    std::memcpy(f4(kOffPos), rd.take((size_t)W * kD), sizeof(float) * W * kD);
+    pack_matrix(rd.take(kD * kD), kD, kD, kD, f4(kOffScW));
+    pack_vector(rd.take(kD), kD, kD, f4(kOffConvV + kVScB * kVec64));
+    std::vector<float> sc, sh;
+    {
+        const float* k = rd.take(3 * kD * kD);
+        for (int t = 0; t < 3; ++t) pack_matrix(k + (size_t)t * kD * kD, kD, kD, kD, f4(kOffC3aW + t * kMat64));
+        pack_vector(rd.take(kD), kD, kD, f4(kOffConvV + kVC3aB * kVec64));
+        const float* g = rd.take(kD); const float* b = rd.take(kD);
+        const float* mu = rd.take(kD); const float* var = rd.take(kD);
+        bn_affine(g, b, mu, var, kD, sc, sh);
+        pack_vector(sc.data(), kD, kD, f4(kOffConvV + kVBn1S * kVec64));
+        pack_vector(sh.data(), kD, kD, f4(kOffConvV + kVBn1T * kVec64));
+    }
+    {
+        const float* k = rd.take(3 * kD * kD);
+        for (int t = 0; t < 3; ++t) pack_matrix(k + (size_t)t * kD * kD, kD, kD, kD, f4(kOffC3bW + t * kMat64));
+        pack_vector(rd.take(kD), kD, kD, f4(kOffConvV + kVC3bB * kVec64));
+        const float* g = rd.take(kD); const float* b = rd.take(kD);
+        const float* mu = rd.take(kD); const float* var = rd.take(kD);
+        bn_affine(g, b, mu, var, kD, sc, sh);
+        pack_vector(sc.data(), kD, kD, f4(kOffConvV + kVBn2S * kVec64));
+        pack_vector(sh.data(), kD, kD, f4(kOffConvV + kVBn2T * kVec64));
+    }
+    for (int blk = 0; blk < 2; ++blk) {
+        const int T = kOffTb + blk * kTbSize;
+        const int wm[4] = {kTbWq, kTbWk, kTbWv, kTbWo};
+        const int bv[4] = {kVBq, kVBk, kVBv, kVBo};
+        for (int i = 0; i < 4; ++i) {
+            pack_matrix(rd.take(kD * kD), kD, kD, kD, f4(T + wm[i]));
+            pack_vector(rd.take(kD), kD, kD, f4(T + kTbVec + bv[i] * kVec64));
+        }
+        pack_matrix(rd.take(kD * kFF), kD, kFF, kFF, f4(T + kTbF1));
+        pack_vector(rd.take(kFF), kFF, kFF, f4(T + kTbB1));
+        pack_matrix(rd.take(kFF * kD), kFF, kD, kD, f4(T + kTbF2));
+        pack_vector(rd.take(kD), kD, kD, f4(T + kTbVec + kVB2 * kVec64));
+        pack_vector(rd.take(kD), kD, kD, f4(T + kTbVec + kVLn1G * kVec64));
+        pack_vector(rd.take(kD), kD, kD, f4(T + kTbVec + kVLn1B * kVec64));
+        pack_vector(rd.take(kD), kD, kD, f4(T + kTbVec + kVLn2G * kVec64));
+        pack_vector(rd.take(kD), kD, kD, f4(T + kTbVec + kVLn2B * kVec64));
+    }
+    pack_vector(rd.take(kD), kD, kD, f4(kOffPoolV));
+    f4(kOffPoolB)[0] = *rd.take(1);
+}
+
+int make_dense(Reader& rd, int K, int N, int n_pad, bool bn, DenseLayer& L) {
+    L.k = K;
+    L.n = N;
+    L.n_pad = n_pad;
+    std::vector<float> w((size_t)K * n_pad), v((size_t)n_pad);
+    pack_matrix(rd.take((size_t)K * N), K, N, n_pad, w.data());
+    int rc = upload(w, &L.d_w);
+    if (rc) return rc;
+    pack_vector(rd.take(N), N, n_pad, v.data());
+    rc = upload(v, &L.d_bias);
+    if (rc) return rc;
+    if (bn) {
+        const float* g = rd.take(N); const float* b = rd.take(N);
+        const float* mu = rd.take(N); const float* var = rd.take(N);
+        std::vector<float> sc, sh;
+        bn_affine(g, b, mu, var, N, sc, sh);
+        pack_vector(sc.data(), N, n_pad, v.data());
+        rc = upload(v, &L.d_scale);
+        if (rc) return rc;
+        pack_vector(sh.data(), N, n_pad, v.data());
+        rc = upload(v, &L.d_shift);
+        if (rc) return rc;
+    }
+    return DPTM_OK;
+}
+
+void free_dense(DenseLayer& L) {
+    if (L.d_w) (void)hipFree(L.d_w);
+    if (L.d_bias) (void)hipFree(L.d_bias);
+    if (L.d_scale) (void)hipFree(L.d_scale);
+    if (L.d_shift) (void)hipFree(L.d_shift);
+    L = DenseLayer();
+}
+
+struct Prof {
+    dptm_handle* h;
+    hipStream_t st;
+    int cls;
+    bool on;
+    hipEvent_t a = nullptr, b = nullptr;
+    Prof(dptm_handle* h_, hipStream_t st_, int cls_) : h(h_), st(st_), cls(cls_), on(h_->prof_armed) {
+        if (on) {
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            (void)hipEventRecord(a, st);
+        }
+    }
+    ~Prof() {
+        if (on) {
+            (void)hipEventRecord(b, st);
+            h->prof.push_back({cls, a, b});
+        }
+    }
+};
+
+int run_dense(dptm_handle* h, const DenseLayer& L, int epi, const float* x, int64_t ldx,
+              const int32_t* row_index, int64_t m, float* out, int64_t ldo, int col_off,
+              hipStream_t st, int cls) {
+    DenseArgs a;
+    a.x = x;
+    a.ldx = ldx;
+    a.row_index = row_index;
+    a.m = m;
+    a.k = L.k;
+    a.n_pad = L.n_pad;
+    a.w = reinterpret_cast<const f32x4_t*>(L.d_w);
+    a.bias = reinterpret_cast<const f32x4_t*>(L.d_bias);
+    a.scale = reinterpret_cast<const f32x4_t*>(L.d_scale);
+    a.shift = reinterpret_cast<const f32x4_t*>(L.d_shift);
+    a.out = out;
+    a.ldo = ldo;
+    a.col_off = col_off;
+    Prof p(h, st, cls);
+    HIP_TRY(launch_dense(a, epi, st));
+    return DPTM_OK;
+}
+
+// One chunk (m <= kChunkSites) of the forward pass, everything device-resident.
+int score_chunk(dptm_handle* h, const uint8_t* const tok[3], const float* strct, const float* esm,
+                int64_t esm_ld, const int32_t* esm_row, int64_t m, float* out, hipStream_t st) {
+    for (int b = 0; b < 3; ++b) {
+        Prof p(h, st, DPTM_PROF_BRANCH21 + b);
+        HIP_TRY(launch_branch(kWin[b], h->d_branch[b], tok[b], m, h->d_concat, kConcat, b * kD, st));
+    }
+    int rc;
+    if ((rc = run_dense(h, h->strct, kEpiSwishAffine, strct, kStruct, nullptr, m, h->d_concat, kConcat,
+                        3 * kD, st, DPTM_PROF_STRUCT)))
+        return rc;
+    if ((rc = run_dense(h, h->esm1, kEpiSwishAffine, esm, esm_ld, esm_row, m, h->d_h1, kEsm1, 0, st,
+                        DPTM_PROF_ESM1)))
+        return rc;
+    if ((rc = run_dense(h, h->esm2, kEpiSwish, h->d_h1, kEsm1, nullptr, m, h->d_concat, kConcat,
+                        3 * kD + kStructUnits, st, DPTM_PROF_ESM2)))
+        return rc;
+    if ((rc = run_dense(h, h->t1, kEpiSwishAffine, h->d_concat, kConcat, nullptr, m, h->d_t1, kT1, 0, st,
+                        DPTM_PROF_TRUNK1)))
+        return rc;
+    if ((rc = run_dense(h, h->t2, kEpiSwishAffine, h->d_t1, kT1, nullptr, m, h->d_t2, kT2, 0, st,
+                        DPTM_PROF_TRUNK2)))
+        return rc;
+    return run_dense(h, h->head, kEpiHead, h->d_t2, kT2, nullptr, m, out, 2, 0, st, DPTM_PROF_HEAD);
+}
+
+int ensure_host_staging(dptm_handle* h) {
+    if (h->s_out) return DPTM_OK;
+    for (int b = 0; b < 3; ++b) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->s_tok[b]), kChunkSites * kWin[b]));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->s_strct), kChunkSites * kStruct * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->s_esm), kChunkSites * (size_t)kEsm * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->s_pos), kChunkSites * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->s_out), kChunkSites * 2 * sizeof(float)));
+    return DPTM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dptm_last_error(void) { return g_err.c_str(); }
+
+int64_t dptm_weight_count(const dptm_spec* spec) {
+    if (!spec_supported(spec)) return fail(DPTM_EINVAL, "dptm_weight_count: unsupported model spec");
+    return weight_count();
+}
+
+void dptm_destroy(dptm_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& r : h->prof) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (int b = 0; b < 3; ++b) {
+        if (h->d_branch[b]) (void)hipFree(h->d_branch[b]);
+        if (h->d_tok[b]) (void)hipFree(h->d_tok[b]);
+        if (h->s_tok[b]) (void)hipFree(h->s_tok[b]);
+    }
+    free_dense(h->strct);
+    free_dense(h->esm1);
+    free_dense(h->esm2);
+    free_dense(h->t1);
+    free_dense(h->t2);
+    free_dense(h->head);
+    void* bufs[] = {h->d_concat, h->d_h1, h->d_t1, h->d_t2, h->d_zero_row, h->d_esm_row, h->s_strct,
+                    h->s_esm, h->s_out, h->s_codes, h->s_table, h->s_pos};
+    for (void* p : bufs)
+        if (p) (void)hipFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int dptm_create(const void* weights, size_t nbytes, const dptm_spec* spec, int device, dptm_handle** out) {
+    if (!out) return fail(DPTM_EINVAL, "dptm_create: out is NULL");
+    *out = nullptr;
+    if (!weights) return fail(DPTM_EINVAL, "dptm_create: weights is NULL");
+    if (!spec_supported(spec))
+        return fail(DPTM_EINVAL, "dptm_create: unsupported model spec (only the reference shape "
+                                 "windows 21/33/51, embed 64, 4 heads, ff 256, esm 1280 is built)");
+    const int64_t want = weight_count();
+    if ((int64_t)(nbytes / sizeof(float)) != want || nbytes % sizeof(float) != 0) {
+        char msg[160];
+        std::snprintf(msg, sizeof msg, "dptm_create: weight blob has %zu bytes, expected %lld", nbytes,
+                      (long long)(want * (int64_t)sizeof(float)));
+        return fail(DPTM_EINVAL, msg);
+    }
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(DPTM_EINVAL, "dptm_create: no such device");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(DPTM_EINVAL, std::string("dptm_create: kernels are built for gfx950, device is ") +
+                                     prop.gcnArchName);
+
+    dptm_handle* h = new (std::nothrow) dptm_handle();
+    if (!h) return fail(DPTM_ENOMEM, "dptm_create: out of host memory");
+    h->device = device;
+    int rc = DPTM_OK;
+    auto bail = [&](int code) {
+        std::string keep = g_err;
+        dptm_destroy(h);
+        g_err = keep;
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(DPTM_EHIP, "dptm_create: hipStreamCreate failed"));
+
+    Reader rd{static_cast<const float*>(weights)};
+    std::vector<float> buf;
+    for (int b = 0; b < 3; ++b) {
+        pack_branch(rd, kWin[b], buf);
+        if ((rc = upload(buf, &h->d_branch[b]))) return bail(rc);
+    }
+    if ((rc = make_dense(rd, kStruct, kStructUnits, kStructUnits, true, h->strct))) return bail(rc);
+    if ((rc = make_dense(rd, kEsm, kEsm1, kEsm1, true, h->esm1))) return bail(rc);
+    if ((rc = make_dense(rd, kEsm1, kEsm2, kEsm2, false, h->esm2))) return bail(rc);
+    if ((rc = make_dense(rd, kConcat, kT1, kT1, true, h->t1))) return bail(rc);
+    if ((rc = make_dense(rd, kT1, kT2, kT2, true, h->t2))) return bail(rc);
+    if ((rc = make_dense(rd, kT2, 2, 32, false, h->head))) return bail(rc);
+    if (rd.p - static_cast<const float*>(weights) != want)
+        return bail(fail(DPTM_EINVAL, "dptm_create: internal weight-order mismatch"));
+
+    auto dalloc = [&](void** p, size_t bytes) -> int {
+        if (hipMalloc(p, bytes) != hipSuccess) return fail(DPTM_ENOMEM, "dptm_create: device allocation failed");
+        return DPTM_OK;
+    };
+    if ((rc = dalloc((void**)&h->d_concat, kChunkSites * (size_t)kConcat * 4))) return bail(rc);
+    if ((rc = dalloc((void**)&h->d_h1, kChunkSites * (size_t)kEsm1 * 4))) return bail(rc);
+    if ((rc = dalloc((void**)&h->d_t1, kChunkSites * (size_t)kT1 * 4))) return bail(rc);
+    if ((rc = dalloc((void**)&h->d_t2, kChunkSites * (size_t)kT2 * 4))) return bail(rc);
+    if ((rc = dalloc((void**)&h->d_zero_row, kEsm * 4))) return bail(rc);
+    if (hipMemset(h->d_zero_row, 0, kEsm * 4) != hipSuccess) return bail(fail(DPTM_EHIP, "hipMemset failed"));
+    for (int b = 0; b < 3; ++b)
+        if ((rc = dalloc((void**)&h->d_tok[b], kChunkSites * (size_t)kWin[b]))) return bail(rc);
+    if ((rc = dalloc((void**)&h->d_esm_row, kChunkSites * sizeof(int32_t)))) return bail(rc);
+    if (hipDeviceSynchronize() != hipSuccess) return bail(fail(DPTM_EHIP, "dptm_create: device sync failed"));
+    *out = h;
+    return DPTM_OK;
+}
+
+int64_t dptm_chunk_sites(const dptm_handle* h) { return h ? kChunkSites : 0; }
+
+int dptm_sync(dptm_handle* h) {
+    if (!h) return fail(DPTM_EINVAL, "dptm_sync: NULL handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return DPTM_OK;
+}
+
+int dptm_score_device(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
+                      const float* strct, const float* esm, int64_t n, float* out, void* stream) {
+    if (!h) return fail(DPTM_EINVAL, "dptm_score_device: NULL handle");
+    if (n < 0) return fail(DPTM_EINVAL, "dptm_score_device: n < 0");
+    if (n == 0) return DPTM_OK;
+    if (!tok21 || !tok33 || !tok51 || !strct || !esm || !out)
+        return fail(DPTM_EINVAL, "dptm_score_device: NULL buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    for (int64_t c0 = 0; c0 < n; c0 += kChunkSites) {
+        const int64_t m = n - c0 < kChunkSites ? n - c0 : kChunkSites;
+        const uint8_t* tok[3] = {tok21 + c0 * 21, tok33 + c0 * 33, tok51 + c0 * 51};
+        int rc = score_chunk(h, tok, strct + c0 * kStruct, esm + c0 * (int64_t)kEsm, kEsm, nullptr, m,
+                             out + c0 * 2, st);
+        if (rc) return rc;
+    }
+    return DPTM_OK;
+}
+
+int dptm_assemble_device(dptm_handle* h, const uint8_t* codes, int64_t L, int64_t esm_rows,
+                         const int32_t* positions, int64_t n, uint8_t* tok21, uint8_t* tok33,
+                         uint8_t* tok51, int32_t* esm_row, void* stream) {
+    if (!h) return fail(DPTM_EINVAL, "dptm_assemble_device: NULL handle");
+    if (n < 0 || L < 0 || esm_rows < 0) return fail(DPTM_EINVAL, "dptm_assemble_device: negative size");
+    if (n == 0) return DPTM_OK;
+    if (!codes || !positions || !tok21 || !tok33 || !tok51 || !esm_row)
+        return fail(DPTM_EINVAL, "dptm_assemble_device: NULL buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    Prof p(h, st, DPTM_PROF_ASSEMBLE);
+    HIP_TRY(launch_assemble(codes, L, esm_rows, positions, n, tok21, tok33, tok51, esm_row, st));
+    return DPTM_OK;
+}
+
+int dptm_score_protein_device(dptm_handle* h, const uint8_t* codes, int64_t L, const float* esm_table,
+                              int64_t esm_rows, const int32_t* positions, const float* strct, int64_t n,
+                              float* out, void* stream) {
+    if (!h) return fail(DPTM_EINVAL, "dptm_score_protein_device: NULL handle");
+    if (n < 0 || L < 0 || esm_rows < 0) return fail(DPTM_EINVAL, "dptm_score_protein_device: negative size");
+    if (n == 0) return DPTM_OK;
+    if (!codes || !positions || !strct || !out || (esm_rows > 0 && !esm_table))
+        return fail(DPTM_EINVAL, "dptm_score_protein_device: NULL buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    const float* table = esm_rows > 0 ? esm_table : h->d_zero_row;
+    for (int64_t c0 = 0; c0 < n; c0 += kChunkSites) {
+        const int64_t m = n - c0 < kChunkSites ? n - c0 : kChunkSites;
+        int rc = dptm_assemble_device(h, codes, L, esm_rows, positions + c0, m, h->d_tok[0], h->d_tok[1],
+                                      h->d_tok[2], h->d_esm_row, st);
+        if (rc) return rc;
+        const uint8_t* tok[3] = {h->d_tok[0], h->d_tok[1], h->d_tok[2]};
+        rc = score_chunk(h, tok, strct + c0 * kStruct, table, kEsm, h->d_esm_row, m, out + c0 * 2, st);
+        if (rc) return rc;
+    }
+    return DPTM_OK;
+}
+
+int dptm_score(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
+               const float* strct, const float* esm, int64_t n, float* out) {
+    if (!h) return fail(DPTM_EINVAL, "dptm_score: NULL handle");
+    if (n < 0) return fail(DPTM_EINVAL, "dptm_score: n < 0");
+    if (n == 0) return DPTM_OK;
+    if (!tok21 || !tok33 || !tok51 || !strct || !esm || !out) return fail(DPTM_EINVAL, "dptm_score: NULL buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = ensure_host_staging(h);
+    if (rc) return rc;
+    const uint8_t* tk[3] = {tok21, tok33, tok51};
+    for (int64_t c0 = 0; c0 < n; c0 += kChunkSites) {
+        const int64_t m = n - c0 < kChunkSites ? n - c0 : kChunkSites;
+        for (int b = 0; b < 3; ++b)
+            HIP_TRY(hipMemcpyAsync(h->s_tok[b], tk[b] + c0 * kWin[b], m * kWin[b], hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->s_strct, strct + c0 * kStruct, m * kStruct * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->s_esm, esm + c0 * (int64_t)kEsm, m * (size_t)kEsm * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        const uint8_t* tok[3] = {h->s_tok[0], h->s_tok[1], h->s_tok[2]};
+        rc = score_chunk(h, tok, h->s_strct, h->s_esm, kEsm, nullptr, m, h->s_out, h->stream);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(out + c0 * 2, h->s_out, m * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return DPTM_OK;
+}
+
+int dptm_score_protein(dptm_handle* h, const uint8_t* codes, int64_t L, const float* esm_table,
+                       int64_t esm_rows, const int32_t* positions, const float* strct, int64_t n,
+                       float* out) {
+    if (!h) return fail(DPTM_EINVAL, "dptm_score_protein: NULL handle");
+    if (n < 0 || L < 0 || esm_rows < 0) return fail(DPTM_EINVAL, "dptm_score_protein: negative size");
+    if (n == 0) return DPTM_OK;
+    if (!codes || !positions || !strct || !out || (esm_rows > 0 && !esm_table))
+        return fail(DPTM_EINVAL, "dptm_score_protein: NULL buffer");
+    for (int64_t i = 0; i < n; ++i)
+        if (positions[i] < 1 || positions[i] > L) {
+            char msg[128];
+            std::snprintf(msg, sizeof msg, "dptm_score_protein: position %d (index %lld) outside 1..%lld",
+                          positions[i], (long long)i, (long long)L);
+            return fail(DPTM_EINVAL, msg);
+        }
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = ensure_host_staging(h);
+    if (rc) return rc;
+    if (L > h->s_codes_cap) {
+        if (h->s_codes) (void)hipFree(h->s_codes);
+        h->s_codes = nullptr;
+        h->s_codes_cap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->s_codes), (size_t)L));
+        h->s_codes_cap = L;
+    }
+    if (esm_rows > h->s_table_cap) {
+        if (h->s_table) (void)hipFree(h->s_table);
+        h->s_table = nullptr;
+        h->s_table_cap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->s_table), (size_t)esm_rows * kEsm * sizeof(float)));
+        h->s_table_cap = esm_rows;
+    }
+    HIP_TRY(hipMemcpyAsync(h->s_codes, codes, (size_t)L, hipMemcpyHostToDevice, h->stream));
+    if (esm_rows > 0)
+        HIP_TRY(hipMemcpyAsync(h->s_table, esm_table, (size_t)esm_rows * kEsm * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    for (int64_t c0 = 0; c0 < n; c0 += kChunkSites) {
+        const int64_t m = n - c0 < kChunkSites ? n - c0 : kChunkSites;
+        HIP_TRY(hipMemcpyAsync(h->s_pos, positions + c0, m * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->s_strct, strct + c0 * kStruct, m * kStruct * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        rc = dptm_score_protein_device(h, h->s_codes, L, h->s_table, esm_rows, h->s_pos, h->s_strct, m,
+                                       h->s_out, h->stream);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(out + c0 * 2, h->s_out, m * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return DPTM_OK;
+}
+
+int dptm_profile_begin(dptm_handle* h) {
+    if (!h) return fail(DPTM_EINVAL, "dptm_profile_begin: NULL handle");
+    for (auto& r : h->prof) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    h->prof.clear();
+    h->prof_armed = true;
+    return DPTM_OK;
+}
+
+int dptm_profile_end(dptm_handle* h, float* ms, int64_t* launches) {
+    if (!h || !ms || !launches) return fail(DPTM_EINVAL, "dptm_profile_end: NULL argument");
+    h->prof_armed = false;
+    HIP_TRY(hipSetDevice(h->device));
+    for (int i = 0; i < DPTM_PROF_COUNT; ++i) {
+        ms[i] = 0.f;
+        launches[i] = 0;
+    }
+    int rc = DPTM_OK;
+    for (auto& r : h->prof) {
+        float t = 0.f;
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, r.a, r.b);
+        if (e != hipSuccess && rc == DPTM_OK)
+            rc = fail(DPTM_EHIP, std::string("dptm_profile_end: ") + hipGetErrorString(e));
+        ms[r.cls] += t;
+        launches[r.cls] += 1;
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    h->prof.clear();
+    return rc;
+}
+
+}  // extern "C"

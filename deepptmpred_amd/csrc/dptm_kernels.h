@@ -1,0 +1,36 @@
+// Launcher interface between the C ABI (dptm_api.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace dptm {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+enum DenseEpilogue { kEpiSwish = 0, kEpiSwishAffine = 1, kEpiHead = 2 };
+
+struct DenseArgs {
+    const float* x;            // [rows][ldx] fp32 activations
+    int64_t ldx;               // floats per row of x
+    const int32_t* row_index;  // optional gather: source row of output row r, <0 = zero row
+    int64_t m;                 // output rows
+    int k;                     // contraction length, multiple of 8
+    int n_pad;                 // out features padded to the packed width
+    const f32x4_t* w;          // packed weights [n_pad/32][k/8][64] float4
+    const f32x4_t* bias;       // packed vector (n_pad)
+    const f32x4_t* scale;      // packed vector, kEpiSwishAffine only
+    const f32x4_t* shift;
+    float* out;                // [rows][ldo]
+    int64_t ldo;
+    int col_off;
+};
+
+hipError_t launch_branch(int w, const float* params, const uint8_t* tok, int64_t n, float* out,
+                         int ldo, int col_off, hipStream_t st);
+hipError_t launch_dense(const DenseArgs& a, int epi, hipStream_t st);
+hipError_t launch_assemble(const uint8_t* codes, int64_t L, int64_t esm_rows,
+                           const int32_t* positions, int64_t n, uint8_t* t21, uint8_t* t33,
+                           uint8_t* t51, int32_t* esm_row, hipStream_t st);
+
+}  // namespace dptm

@@ -1,0 +1,655 @@
+// HIP kernels (gfx950 / CDNA4) for DeepPTMPred's site-scoring path.
+//
+//  branch_kernel<W>   one fused launch per window size: embedding + position add,
+//                     residual conv block, two transformer blocks and attention pooling
+//                     (reference graph: pred/train_PTM/model.py:157-182), fp32 throughout.
+//  dense_kernel<..>   Y = epilogue(X*W + b) for the per-site dense layers
+//                     (model.py:187-208): struct branch, ESM branch, trunk and head.
+//  assemble_kernel    window assembly (pred/train_PTM/predict.py:487-501, 529-560).
+//
+// All matrix products run on v_mfma_f32_32x32x2_f32 in the transposed orientation
+// Y^T = W^T * X^T, so that the data row sits on the lane and features sit on
+// (register, half-wave); see dptm_layout.h for the register map ("chain layout").
+#include <hip/hip_runtime.h>
+
+#include "dptm_layout.h"
+#include "dptm_kernels.h"
+
+namespace dptm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void mfma(f32x16& acc, float a, float b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// keras 'swish': x * sigmoid(x)
+__device__ __forceinline__ float swishf(float x) { return x * fast_rcp(1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32); }
+
+// Exchange between the two half-waves: returns {a.lo|b.lo , a.hi|b.hi} (see
+// v_permlane32_swap: lanes 32-63 of the first operand swap with lanes 0-31 of the second).
+__device__ __forceinline__ void half_swap(float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+
+// acc tile t (16 regs) <-> feature groups u = 4t..4t+3 of the chain layout
+template <int NT>
+__device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[NT], const f32x4* __restrict__ vec,
+                                              int h, int groups_per_half) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 b = vec[h * groups_per_half + 4 * t + g];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][4 * g + e] = b[e];
+        }
+}
+
+// acc[t] += W^T-tile(t) * X^T with X held in registers (chain layout, K8 groups of 8 feats)
+template <int K8, int NT>
+__device__ __forceinline__ void gemm_regs(f32x16 (&acc)[NT], const f32x4* __restrict__ wp,
+                                          const f32x4 (&x)[K8], int lane) {
+#pragma unroll
+    for (int u = 0; u < K8; ++u) {
+        f32x4 a[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[t] = wp[(t * K8 + u) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) mfma(acc[t], a[t][e], x[u][e]);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void acc_to_x(const f32x16 (&acc)[NT], f32x4 (&x)[4 * NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[4 * t + g][e] = acc[t][4 * g + e];
+}
+
+// keras LayerNormalization(epsilon=1e-6) over the 64 features of each row
+__device__ __forceinline__ void layernorm64(f32x4 (&x)[8], const f32x4* __restrict__ g,
+                                            const f32x4* __restrict__ b, int h) {
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (x[u][0] + x[u][1]) + (x[u][2] + x[u][3]);
+    const float mean = xhalf_sum(s) * (1.0f / 64.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = x[u][e] - mean;
+            x[u][e] = d;
+            q = fmaf(d, d, q);
+        }
+    const float var = xhalf_sum(q) * (1.0f / 64.0f);
+    const float inv = rsqrtf(var + 1e-6f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const f32x4 gg = g[h * 8 + u], bb = b[h * 8 + u];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[u][e] = fmaf(x[u][e] * inv, gg[e], bb[e]);
+    }
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------
+// Fused sequence branch.  One workgroup = 8 wavefronts = one tile of S = 256/W whole
+// sites (S*W <= 256 rows, row = site_in_tile*W + position); wavefront w owns rows
+// 32w..32w+31 for every row-wise layer.  LDS holds two [256][68] fp32 images:
+//   conv phase:  bufA = embedded input, bufB = first conv output (neighbour rows are
+//                read by the 3-tap convolutions);
+//   transformer: bufA = K, bufB = V of the whole tile (attention reads other rows of
+//                the same site); Q, the residual stream and the FFN hidden layer stay
+//                in registers;
+//   pooling:     bufA = final activations, plus one score per row.
+// ------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P,
+                                                     const uint8_t* __restrict__ tok,
+                                                     int64_t n_sites, float* __restrict__ out,
+                                                     int ldo, int col_off) {
+    constexpr int S = kTileRows / W;  // sites per tile
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* bufA = lds;
+    float* bufB = lds + kTileRows * kLdsStride;
+    float* score = bufB + kTileRows * kLdsStride;  // [256]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int h = lane >> 5;
+    const int j = lane & 31;
+    const int64_t site0 = (int64_t)blockIdx.x * S;
+    const int sites_here = (int)min((int64_t)S, n_sites - site0);
+    const int rows_valid = sites_here * W;
+
+    // ---- embedding + position embedding -> bufA   (model.py:157-158)
+    for (int idx = tid; idx < kTileRows * 16; idx += 512) {
+        const int r = idx >> 4, c4 = idx & 15;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows_valid) {
+            const int s = r / W, p = r - s * W;
+            int t = tok[(site0 + s) * W + p];
+            t = t > kCodes - 1 ? kCodes - 1 : t;
+            v = P[kOffEmb + t * 16 + c4] + P[kOffPos + p * 16 + c4];
+        }
+        *reinterpret_cast<f32x4*>(bufA + r * kLdsStride + c4 * 4) = v;
+    }
+    __syncthreads();
+
+    const int row = wave * 32 + j;
+    const bool row_ok = row < rows_valid;
+    const int site_l = row_ok ? row / W : 0;
+    const int pos_l = row_ok ? row - site_l * W : 1;
+    const int row_start = site_l * W;  // first row of this lane's site (0 for padding rows)
+    const bool tap0_ok = row_ok && pos_l > 0;
+    const bool tap2_ok = row_ok && pos_l < W - 1;
+
+    f32x4 x1[8];  // residual stream of this lane's row, chain layout
+
+    // ---- residual conv block (model.py:129-141)
+    {
+        const f32x4* cv = P + kOffConvV;
+        f32x16 acc_s[2], acc_a[2];
+        acc_init_bias<2>(acc_s, cv + kVScB * kVec64, h, 8);
+        acc_init_bias<2>(acc_a, cv + kVC3aB * kVec64, h, 8);
+        const float* xc = bufA + row * kLdsStride + 4 * h;
+        const float* xl = tap0_ok ? xc - kLdsStride : xc;
+        const float* xr = tap2_ok ? xc + kLdsStride : xc;
+        const f32x4* wsc = P + kOffScW;
+        const f32x4* wa = P + kOffC3aW;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const f32x4 bc = *reinterpret_cast<const f32x4*>(xc + 8 * u);
+            f32x4 bl = *reinterpret_cast<const f32x4*>(xl + 8 * u);
+            f32x4 br = *reinterpret_cast<const f32x4*>(xr + 8 * u);
+            if (!tap0_ok) bl = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!tap2_ok) br = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 a_sc[2], a0[2], a1[2], a2[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a_sc[t] = wsc[(t * 8 + u) * 64 + lane];
+                a0[t] = wa[0 * kMat64 + (t * 8 + u) * 64 + lane];
+                a1[t] = wa[1 * kMat64 + (t * 8 + u) * 64 + lane];
+                a2[t] = wa[2 * kMat64 + (t * 8 + u) * 64 + lane];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    mfma(acc_s[t], a_sc[t][e], bc[e]);
+                    mfma(acc_a[t], a0[t][e], bl[e]);
+                    mfma(acc_a[t], a1[t][e], bc[e]);
+                    mfma(acc_a[t], a2[t][e], br[e]);
+                }
+        }
+        // y1 = BN1(swish(conv3a)) -> bufB (own rows)
+        f32x4 y[8];
+        acc_to_x<2>(acc_a, y);
+        float* yb = bufB + row * kLdsStride + 4 * h;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const f32x4 sc = cv[kVBn1S * kVec64 + h * 8 + u], sh = cv[kVBn1T * kVec64 + h * 8 + u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[u][e] = fmaf(swishf(y[u][e]), sc[e], sh[e]);
+            *reinterpret_cast<f32x4*>(yb + 8 * u) = y[u];
+        }
+        __syncthreads();
+        // conv3b on bufB
+        f32x16 acc_b[2];
+        acc_init_bias<2>(acc_b, cv + kVC3bB * kVec64, h, 8);
+        const float* yc = bufB + row * kLdsStride + 4 * h;
+        const float* yl = tap0_ok ? yc - kLdsStride : yc;
+        const float* yr = tap2_ok ? yc + kLdsStride : yc;
+        const f32x4* wb = P + kOffC3bW;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            f32x4 bl = *reinterpret_cast<const f32x4*>(yl + 8 * u);
+            f32x4 br = *reinterpret_cast<const f32x4*>(yr + 8 * u);
+            if (!tap0_ok) bl = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!tap2_ok) br = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 a0[2], a1[2], a2[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a0[t] = wb[0 * kMat64 + (t * 8 + u) * 64 + lane];
+                a1[t] = wb[1 * kMat64 + (t * 8 + u) * 64 + lane];
+                a2[t] = wb[2 * kMat64 + (t * 8 + u) * 64 + lane];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    mfma(acc_b[t], a0[t][e], bl[e]);
+                    mfma(acc_b[t], a1[t][e], y[u][e]);
+                    mfma(acc_b[t], a2[t][e], br[e]);
+                }
+        }
+        f32x4 s[8];
+        acc_to_x<2>(acc_b, x1);
+        acc_to_x<2>(acc_s, s);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const f32x4 sc = cv[kVBn2S * kVec64 + h * 8 + u], sh = cv[kVBn2T * kVec64 + h * 8 + u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x1[u][e] = fmaf(swishf(x1[u][e]), sc[e], sh[e]) + s[u][e];
+        }
+    }
+
+    // ---- two transformer blocks (model.py:93-118, 172-173)
+#pragma unroll 1
+    for (int blk = 0; blk < 2; ++blk) {
+        const f32x4* T = P + kOffTb + blk * kTbSize;
+        const f32x4* tv = T + kTbVec;
+        // every wave is done reading bufA/bufB (conv taps, or the previous block's K/V)
+        __syncthreads();
+        {
+            f32x16 acc[2];
+            acc_init_bias<2>(acc, tv + kVBk * kVec64, h, 8);
+            gemm_regs<8, 2>(acc, T + kTbWk, x1, lane);
+            float* kb = bufA + row * kLdsStride + 4 * h;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(kb + 8 * (4 * t + g)) =
+                        f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+            acc_init_bias<2>(acc, tv + kVBv * kVec64, h, 8);
+            gemm_regs<8, 2>(acc, T + kTbWv, x1, lane);
+            float* vb = bufB + row * kLdsStride + 4 * h;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(vb + 8 * (4 * t + g)) =
+                        f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+        }
+        // q, scaled by 1/sqrt(head_dim) = 1/4 (exact), regrouped so that the lower
+        // half-wave holds heads 0,1 and the upper half-wave heads 2,3 of its row
+        float qa[16], qb[16];
+        {
+            f32x16 acc[2];
+            acc_init_bias<2>(acc, tv + kVBq * kVec64, h, 8);
+            gemm_regs<8, 2>(acc, T + kTbWq, x1, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                qa[r] = acc[0][r] * 0.25f;
+                qb[r] = acc[1][r] * 0.25f;
+                half_swap(qa[r], qb[r]);
+            }
+        }
+        __syncthreads();  // K and V of the whole tile are in LDS
+        // attention: this lane = (query row, two heads).  After the regrouping,
+        // qa[4u+e] / qb[4u+e] hold features 32h + 8u + e / 32h + 8u + 4 + e.
+#pragma unroll
+        for (int hd = 0; hd < 2; ++hd) {
+            const float* kp = bufA + row_start * kLdsStride + 32 * h + 16 * hd;
+            const float* vp = bufB + row_start * kLdsStride + 32 * h + 16 * hd;
+            float sc[W];
+            float m = -3.0e38f;
+#pragma unroll
+            for (int t = 0; t < W; ++t) {
+                const f32x4 k0 = *reinterpret_cast<const f32x4*>(kp + t * kLdsStride);
+                const f32x4 k1 = *reinterpret_cast<const f32x4*>(kp + t * kLdsStride + 4);
+                const f32x4 k2 = *reinterpret_cast<const f32x4*>(kp + t * kLdsStride + 8);
+                const f32x4 k3 = *reinterpret_cast<const f32x4*>(kp + t * kLdsStride + 12);
+                float a = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a = fmaf(qa[8 * hd + e], k0[e], a);
+                    a = fmaf(qb[8 * hd + e], k1[e], a);
+                    a = fmaf(qa[8 * hd + 4 + e], k2[e], a);
+                    a = fmaf(qb[8 * hd + 4 + e], k3[e], a);
+                }
+                sc[t] = a;
+                m = fmaxf(m, a);
+            }
+            float den = 0.f;
+#pragma unroll
+            for (int t = 0; t < W; ++t) {
+                sc[t] = __expf(sc[t] - m);
+                den += sc[t];
+            }
+            float o0[4] = {0.f, 0.f, 0.f, 0.f}, o1[4] = {0.f, 0.f, 0.f, 0.f};
+            float o2[4] = {0.f, 0.f, 0.f, 0.f}, o3[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < W; ++t) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(vp + t * kLdsStride);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(vp + t * kLdsStride + 4);
+                const f32x4 v2 = *reinterpret_cast<const f32x4*>(vp + t * kLdsStride + 8);
+                const f32x4 v3 = *reinterpret_cast<const f32x4*>(vp + t * kLdsStride + 12);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o0[e] = fmaf(sc[t], v0[e], o0[e]);
+                    o1[e] = fmaf(sc[t], v1[e], o1[e]);
+                    o2[e] = fmaf(sc[t], v2[e], o2[e]);
+                    o3[e] = fmaf(sc[t], v3[e], o3[e]);
+                }
+            }
+            const float rden = 1.0f / den;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                qa[8 * hd + e] = o0[e] * rden;
+                qb[8 * hd + e] = o1[e] * rden;
+                qa[8 * hd + 4 + e] = o2[e] * rden;
+                qb[8 * hd + 4 + e] = o3[e] * rden;
+            }
+        }
+        // back to the chain layout, output projection, residual, LayerNorm 1
+        f32x4 hres[8];
+        {
+            f32x4 o[8];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                half_swap(qa[r], qb[r]);
+                o[r >> 2][r & 3] = qa[r];
+                o[4 + (r >> 2)][r & 3] = qb[r];
+            }
+            f32x16 acc[2];
+            acc_init_bias<2>(acc, tv + kVBo * kVec64, h, 8);
+            gemm_regs<8, 2>(acc, T + kTbWo, o, lane);
+            acc_to_x<2>(acc, hres);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) hres[u] += x1[u];
+            layernorm64(hres, tv + kVLn1G * kVec64, tv + kVLn1B * kVec64, h);
+        }
+        // FFN 64 -> 256 (swish) -> 64 in two hidden halves of 128, residual, LayerNorm 2
+        {
+            f32x16 acc_o[2];
+            acc_init_bias<2>(acc_o, tv + kVB2 * kVec64, h, 8);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                f32x16 acc_h[4];
+                // hidden tiles 4c..4c+3 <-> bias groups 16c..16c+15 of the 256-vector
+                acc_init_bias<4>(acc_h, T + kTbB1 + 16 * c, h, 32);
+                gemm_regs<8, 4>(acc_h, T + kTbF1 + (4 * c) * 8 * 64, hres, lane);
+                f32x4 hid[16];
+                acc_to_x<4>(acc_h, hid);
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hid[u][e] = swishf(hid[u][e]);
+                // second layer: K = 256 -> 32 groups per out tile; this half is groups 16c..
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    f32x4 a[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) a[t] = T[kTbF2 + (t * 32 + 16 * c + u) * 64 + lane];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) mfma(acc_o[t], a[t][e], hid[u][e]);
+                }
+            }
+            acc_to_x<2>(acc_o, x1);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x1[u] += hres[u];
+            layernorm64(x1, tv + kVLn2G * kVec64, tv + kVLn2B * kVec64, h);
+        }
+    }
+
+    // ---- attention pooling (model.py:176-182)
+    {
+        float part = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const f32x4 wv = P[kOffPoolV + h * 8 + u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part = fmaf(x1[u][e], wv[e], part);
+        }
+        const float sc = tanhf(xhalf_sum(part) + P[kOffPoolB][0]);
+        __syncthreads();  // all attention reads of bufA are finished
+        float* xb = bufA + row * kLdsStride + 4 * h;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x4*>(xb + 8 * u) = x1[u];
+        if (h == 0) score[row] = sc;
+        __syncthreads();
+        for (int o = tid; o < sites_here * 64; o += 512) {
+            const int s = o >> 6, f = o & 63;
+            const float* sp = score + s * W;
+            float m = sp[0];
+#pragma unroll
+            for (int t = 1; t < W; ++t) m = fmaxf(m, sp[t]);
+            float den = 0.f, acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < W; ++t) {
+                const float e = __expf(sp[t] - m);
+                den += e;
+                acc = fmaf(e, bufA[(s * W + t) * kLdsStride + f], acc);
+            }
+            out[(site0 + s) * ldo + col_off + f] = acc / den;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Per-site dense layer: out[r][col_off + n] = epi(sum_k X[src(r)][k] * Wt[k][n] + b[n]).
+// One wavefront computes 64 rows x (NT*32) columns; a workgroup = 4 wavefronts = 256
+// rows of one column slab (blockIdx.y), so its wavefronts share the weight stream.
+// ------------------------------------------------------------------------------------
+template <int NT, int EPI>
+__global__ __launch_bounds__(256) void dense_kernel(DenseArgs p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    if (r0 >= p.m) return;
+    const int slab = blockIdx.y;
+    const int k8 = p.k >> 3;
+    const f32x4* wp = p.w + (size_t)slab * NT * k8 * 64;
+
+    const float* xrow[2];
+    bool ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int64_t r = r0 + 32 * i + j;
+        if (r > p.m - 1) r = p.m - 1;
+        int64_t src = r;
+        ok[i] = true;
+        if (p.row_index) {
+            const int32_t s = p.row_index[r];
+            ok[i] = s >= 0;
+            src = s >= 0 ? s : 0;
+        }
+        xrow[i] = p.x + src * p.ldx + 4 * h;
+    }
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = p.bias[h * (p.n_pad >> 3) + slab * NT * 4 + 4 * t + g];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][t][4 * g + e] = b[e];
+                acc[1][t][4 * g + e] = b[e];
+            }
+        }
+
+    f32x4 a_n[NT], b_n[2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) a_n[t] = wp[(t * k8) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b_n[i] = *reinterpret_cast<const f32x4*>(xrow[i]);
+    for (int u = 0; u < k8; ++u) {
+        f32x4 a[NT], b[2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[t] = a_n[t];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) b[i] = ok[i] ? b_n[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (u + 1 < k8) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a_n[t] = wp[(t * k8 + u + 1) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                b_n[i] = *reinterpret_cast<const f32x4*>(xrow[i] + 8 * (u + 1));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                mfma(acc[0][t], a[t][e], b[0][e]);
+                mfma(acc[1][t], a[t][e], b[1][e]);
+            }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t r = r0 + 32 * i + j;
+        if (r >= p.m) continue;
+        if (EPI == kEpiHead) {
+            // logits 0,1 sit in registers 0,1 of the lower half-wave; softmax over 2
+            if (h == 0) {
+                const float l0 = acc[i][0][0], l1 = acc[i][0][1];
+                const float m = fmaxf(l0, l1);
+                const float e0 = __expf(l0 - m), e1 = __expf(l1 - m);
+                const float rs = 1.0f / (e0 + e1);
+                float2 o = {e0 * rs, e1 * rs};
+                *reinterpret_cast<float2*>(p.out + r * p.ldo) = o;
+            }
+        } else {
+            float* orow = p.out + r * p.ldo + p.col_off + slab * NT * 32 + 4 * h;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {acc[i][t][4 * g], acc[i][t][4 * g + 1], acc[i][t][4 * g + 2],
+                               acc[i][t][4 * g + 3]};
+                    const int vi = h * (p.n_pad >> 3) + slab * NT * 4 + 4 * t + g;
+                    if (EPI == kEpiSwish || EPI == kEpiSwishAffine) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = swishf(v[e]);
+                    }
+                    if (EPI == kEpiSwishAffine) {
+                        const f32x4 sc = p.scale[vi], sh = p.shift[vi];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+                    }
+                    *reinterpret_cast<f32x4*>(orow + 32 * t + 8 * g) = v;
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Window assembly (predict.py:529-560): column c of the window of 1-based position
+// `pos` is sequence index pos-1-half+c, or the padding code 20 outside 0..L-1.
+// One thread per output byte of the widest layout; rows are contiguous so the byte
+// stores of a wavefront coalesce.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void assemble_kernel(const uint8_t* __restrict__ codes, int64_t L,
+                                                       int64_t esm_rows,
+                                                       const int32_t* __restrict__ positions,
+                                                       int64_t n, uint8_t* __restrict__ t21,
+                                                       uint8_t* __restrict__ t33,
+                                                       uint8_t* __restrict__ t51,
+                                                       int32_t* __restrict__ esm_row) {
+    const int64_t total = n * (21 + 33 + 51);
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        uint8_t* dst;
+        int w;
+        int64_t local;
+        if (idx < n * 21) {
+            dst = t21; w = 21; local = idx;
+        } else if (idx < n * (21 + 33)) {
+            dst = t33; w = 33; local = idx - n * 21;
+        } else {
+            dst = t51; w = 51; local = idx - n * (21 + 33);
+        }
+        const int64_t site = local / w;
+        const int c = (int)(local - site * w);
+        const int64_t pos = positions[site];
+        const int64_t i = pos - 1 - (w - 1) / 2 + c;
+        uint8_t code = 20;
+        if (i >= 0 && i < L) {
+            code = codes[i];
+            if (code > 20) code = 20;
+        }
+        dst[local] = code;
+        if (w == 21 && c == 0) esm_row[site] = (pos - 1 < esm_rows) ? (int32_t)(pos - 1) : -1;
+    }
+}
+
+// ------------------------------------------------------------------------------------ launchers
+
+static constexpr size_t kBranchLds = (2 * kTileRows * kLdsStride + kTileRows) * sizeof(float);
+
+template <int W>
+static hipError_t launch_branch_t(const float* params, const uint8_t* tok, int64_t n, float* out,
+                                  int ldo, int col_off, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&branch_kernel<W>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)kBranchLds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    constexpr int S = kTileRows / W;
+    const int64_t blocks = (n + S - 1) / S;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(branch_kernel<W>, dim3((unsigned)blocks), dim3(512), kBranchLds, st,
+                       reinterpret_cast<const f32x4*>(params), tok, n, out, ldo, col_off);
+    return hipGetLastError();
+}
+
+hipError_t launch_branch(int w, const float* params, const uint8_t* tok, int64_t n, float* out,
+                         int ldo, int col_off, hipStream_t st) {
+    switch (w) {
+        case 21: return launch_branch_t<21>(params, tok, n, out, ldo, col_off, st);
+        case 33: return launch_branch_t<33>(params, tok, n, out, ldo, col_off, st);
+        case 51: return launch_branch_t<51>(params, tok, n, out, ldo, col_off, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
+    if (a.m == 0) return hipSuccess;
+    const unsigned gx = (unsigned)((a.m + 255) / 256);
+    if (epi == kEpiHead) {
+        hipLaunchKernelGGL((dense_kernel<1, kEpiHead>), dim3(gx, 1), dim3(256), 0, st, a);
+    } else {
+        if (a.n_pad % 128 != 0) return hipErrorInvalidValue;
+        const unsigned gy = (unsigned)(a.n_pad / 128);
+        if (epi == kEpiSwish)
+            hipLaunchKernelGGL((dense_kernel<4, kEpiSwish>), dim3(gx, gy), dim3(256), 0, st, a);
+        else if (epi == kEpiSwishAffine)
+            hipLaunchKernelGGL((dense_kernel<4, kEpiSwishAffine>), dim3(gx, gy), dim3(256), 0, st, a);
+        else
+            return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble(const uint8_t* codes, int64_t L, int64_t esm_rows,
+                           const int32_t* positions, int64_t n, uint8_t* t21, uint8_t* t33,
+                           uint8_t* t51, int32_t* esm_row, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    const int64_t total = n * 105;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)blocks), dim3(256), 0, st, codes, L, esm_rows,
+                       positions, n, t21, t33, t51, esm_row);
+    return hipGetLastError();
+}
+
+}  // namespace dptm

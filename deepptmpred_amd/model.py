@@ -1,0 +1,176 @@
+"""Drop-in for the Keras model object the reference's predictors hold.
+
+The reference builds its model with ``create_ptm_model(config)``
+(pred/train_PTM/model.py:143-210), restores it with
+``load_model(path, custom_objects={...})`` (predict.py:569-577, case.py:468-476,
+trainer.py:345-353) and scores with ``model.predict([x21, x33, x51, struct, esm])``
+(predict.py:598-599, case.py:495, trainer.py:62).  ``Model`` keeps those call
+signatures; the arithmetic runs in libdptm.so on an MI355X.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _native
+from .spec import (DEFAULT_SPEC, LETTER_CODES, PAD_CODE, ModelSpec, load_flat, pack_blob,
+                   save_flat, synthetic_weights, tensor_table, unpack_blob)
+
+
+def _as_tokens(a, width: int, name: str) -> np.ndarray:
+    """Keras feeds the window arrays to ``Embedding`` (model.py:157), which casts to
+    int32; values must be valid codes 0..20."""
+    a = np.asarray(a)
+    if a.ndim != 2 or a.shape[1] != width:
+        raise ValueError(f"{name}: expected shape [N,{width}], got {a.shape}")
+    if a.dtype.kind == "f":
+        a = a.astype(np.int32)  # same truncation as tf.cast(float -> int32)
+    elif a.dtype.kind not in "iu":
+        raise ValueError(f"{name}: expected an integer or float array, got dtype {a.dtype}")
+    if a.size and (a.min() < 0 or a.max() > PAD_CODE):
+        raise ValueError(f"{name}: residue codes must lie in 0..{PAD_CODE}")
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _as_features(a, width: int, name: str) -> np.ndarray:
+    a = np.asarray(a)
+    if a.ndim != 2 or a.shape[1] != width:
+        raise ValueError(f"{name}: expected shape [N,{width}], got {a.shape}")
+    if a.dtype.kind not in "fiu":
+        raise ValueError(f"{name}: expected a numeric array, got dtype {a.dtype}")
+    return np.ascontiguousarray(a, dtype=np.float32)  # keras casts inputs to float32
+
+
+def encode_sequence(sequence: str) -> np.ndarray:
+    """Residue letters -> codes with the table of predict.py:549-553 (unknown -> 20)."""
+    return np.fromiter((LETTER_CODES.get(c, PAD_CODE) for c in sequence), dtype=np.uint8,
+                       count=len(sequence))
+
+
+class Model:
+    """Holds one weight set; ``predict`` mirrors ``keras.Model.predict``."""
+
+    def __init__(self, weights: Dict[str, np.ndarray], spec: ModelSpec = DEFAULT_SPEC,
+                 device: int = 0):
+        self.spec = spec
+        self.device = device
+        self._weights = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items()}
+        self._blob = pack_blob(self._weights, spec)
+        self._scorer: Optional[_native.Scorer] = None
+
+    # -- native handle
+    @property
+    def scorer(self) -> _native.Scorer:
+        if self._scorer is None:
+            self._scorer = _native.Scorer(self._blob, self.spec, self.device)
+        return self._scorer
+
+    def close(self) -> None:
+        if self._scorer is not None:
+            self._scorer.close()
+            self._scorer = None
+
+    # -- keras-like surface
+    def predict(self, x, batch_size: Optional[int] = 32, verbose="auto", **_ignored) -> np.ndarray:
+        """``model.predict([x21, x33, x51, struct, esm])`` -> float32 ``[N,2]``.
+
+        Every site is scored independently, so ``batch_size`` does not change the
+        result; it is accepted for signature compatibility (Keras default 32,
+        trainer.py:62 passes 128) and the library picks its own pass size."""
+        if not isinstance(x, (list, tuple)) or len(x) != 5:
+            raise ValueError("predict expects [x21, x33, x51, struct, esm] (model.py:210 input order)")
+        ws = self.spec.window_sizes
+        toks = [_as_tokens(x[i], ws[i], f"seq_input_{ws[i]}") for i in range(3)]
+        st = _as_features(x[3], self.spec.struct_feature_dim, "struct_input")
+        esm = _as_features(x[4], self.spec.esm_dim, "esm_input")
+        n = len(toks[0])
+        if any(len(a) != n for a in toks[1:] + [st, esm]):
+            raise ValueError("predict: all five inputs must have the same number of rows")
+        if n == 0:
+            return np.zeros((0, self.spec.n_classes), dtype=np.float32)
+        return self.scorer.score(toks[0], toks[1], toks[2], st, esm)
+
+    def __call__(self, x, training=False):
+        return self.predict(x)
+
+    def predict_protein(self, sequence: str, positions: Sequence[int], struct_features,
+                        esm_table=None) -> np.ndarray:
+        """Fused ``prepare_protein_data`` + ``predict`` (predict.py:462-485, 598-599):
+        windows and ESM rows are assembled on the GPU from the raw sequence."""
+        codes = encode_sequence(sequence)
+        pos = np.ascontiguousarray(np.asarray(positions, dtype=np.int64))
+        if pos.ndim != 1:
+            raise ValueError("positions must be one-dimensional")
+        if pos.size and (pos.min() < 1 or pos.max() > len(sequence)):
+            raise IndexError("position outside the sequence (predict.py:535 raises IndexError)")
+        st = _as_features(struct_features, self.spec.struct_feature_dim, "struct_features")
+        if len(st) != len(pos):
+            raise ValueError("struct_features and positions differ in length")
+        table = None
+        if esm_table is not None:
+            table = _as_features(esm_table, self.spec.esm_dim, "esm_table")
+        if pos.size == 0:
+            return np.zeros((0, self.spec.n_classes), dtype=np.float32)
+        return self.scorer.score_protein(codes, table, pos.astype(np.int32), st)
+
+    def get_weights(self) -> List[np.ndarray]:
+        return [self._weights[n].copy() for n, _ in tensor_table(self.spec)]
+
+    def set_weights(self, arrays: Sequence[np.ndarray]) -> None:
+        table = tensor_table(self.spec)
+        if len(arrays) != len(table):
+            raise ValueError(f"set_weights: expected {len(table)} arrays, got {len(arrays)}")
+        new = {}
+        for (name, shape), a in zip(table, arrays):
+            a = np.asarray(a, dtype=np.float32)
+            if a.shape != tuple(shape):
+                raise ValueError(f"set_weights: {name} has shape {a.shape}, expected {shape}")
+            new[name] = a
+        self._weights = new
+        self._blob = pack_blob(new, self.spec)
+        self.close()
+
+    def named_weights(self) -> Dict[str, np.ndarray]:
+        return dict(self._weights)
+
+    def save(self, filepath: str) -> None:
+        save_flat(filepath, self._weights, self.spec)
+
+    def count_params(self) -> int:
+        return int(self._blob.size)
+
+
+def load_model(filepath, custom_objects=None, compile=True, device: int = 0) -> Model:  # noqa: A002
+    """Stand-in for ``tensorflow.keras.models.load_model`` (predict.py:569-577).
+
+    ``custom_objects`` and ``compile`` are accepted and ignored: the custom layers
+    (PositionEmbedding, MultiHeadSelfAttention, TransformerBlock) are built into the
+    native kernels and the loss is not needed for scoring.  Reads the repo's flat
+    ``.dptm`` container; Keras ``.h5`` files go through ``deepptmpred_amd.keras_h5``."""
+    path = os.fspath(filepath)
+    if not os.path.exists(path):
+        raise OSError(f"No file or directory found at {path}")
+    with open(path, "rb") as fh:
+        head = fh.read(8)
+    if head.startswith(b"\x89HDF\r\n\x1a\n"):
+        from .keras_h5 import read_keras_h5  # deferred: pure-python HDF5 subset reader
+        weights = read_keras_h5(path)
+        return Model(weights, DEFAULT_SPEC, device)
+    weights, spec, _ = load_flat(path)
+    return Model(weights, spec, device)
+
+
+def create_ptm_model(config=None, seed: int = 0, device: int = 0) -> Model:
+    """Stand-in for ``create_ptm_model(config)`` (model.py:143): a freshly initialised
+    model.  ``config`` may carry the reference's attribute names; only the reference
+    dimensions are supported."""
+    spec = DEFAULT_SPEC
+    if config is not None:
+        for attr in ("embed_dim", "num_heads", "ff_dim", "esm_dim", "struct_feature_dim", "max_features"):
+            if hasattr(config, attr) and getattr(config, attr) != getattr(spec, attr):
+                raise ValueError(f"create_ptm_model: {attr}={getattr(config, attr)} is not supported")
+        if hasattr(config, "window_sizes") and tuple(config.window_sizes) != spec.window_sizes:
+            raise ValueError("create_ptm_model: window_sizes must be [21, 33, 51]")
+    return Model(synthetic_weights(seed, spec), spec, device)

@@ -1,0 +1,151 @@
+/*
+ * dptm.h -- C ABI of libdptm.so: DeepPTMPred's site-scoring path on MI355X (gfx950).
+ *
+ * The library replaces what the reference reaches through Keras at
+ *   pred/train_PTM/predict.py:569-577  load_model(path, custom_objects=...)   -> dptm_create
+ *   pred/train_PTM/predict.py:598-599  self.model.predict(model_inputs)[:, 1] -> dptm_score
+ *   pred/train_PTM/case.py:468-476,495 (same two calls)
+ *   pred/train_PTM/trainer.py:62       model.predict(X, batch_size=...)       -> dptm_score
+ * and, for the fused form, the host-side feature assembly in front of that call:
+ *   pred/train_PTM/predict.py:487-501  _prepare_esm_features   (ESM row gather)
+ *   pred/train_PTM/predict.py:529-560  _get_sequence_windows + _encode_sequences
+ *                                                                -> dptm_score_protein
+ *
+ * Conventions
+ *   - Every entry point returns 0 on success and a negative DPTM_E* code on failure;
+ *     dptm_last_error() returns a thread-local message for the last failure.
+ *   - The caller owns every input and output buffer.  The library copies the weights
+ *     at create time and owns all device memory it allocates.  No pointer outlives a
+ *     call except the handle.
+ *   - A handle is bound to one GPU and is not thread-safe.  One handle per GPU.
+ *   - "tok" arrays hold residue codes 0..20 (predict.py:549-553; 20 = '*' padding and
+ *     any unknown letter), one byte each, row-major [n][W].
+ *   - Probabilities come back as float32 [n][2], rows in input order; column 1 is the
+ *     "modified" class the reference thresholds at >= 0.5 (predict.py:599,609).
+ */
+#ifndef DPTM_H
+#define DPTM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPTM_OK 0
+#define DPTM_EINVAL (-1)   /* bad argument / unsupported spec / bad position */
+#define DPTM_EHIP (-2)     /* a HIP runtime call failed */
+#define DPTM_ENOMEM (-3)   /* host or device allocation failed */
+
+#define DPTM_MAX_WINDOWS 3
+
+/* Model dimensions (pred/train_PTM/config.py:49-76 = predict.py:163-169).  Only the
+ * reference's shape -- windows {21,33,51}, 21 codes, embed 64, 4 heads, ff 256,
+ * esm 1280, struct 8, units 128/512/256/512/256/2 -- is implemented; any other value
+ * makes dptm_create fail with DPTM_EINVAL. */
+typedef struct dptm_spec {
+    int32_t n_windows;
+    int32_t window_sizes[DPTM_MAX_WINDOWS];
+    int32_t max_features;
+    int32_t embed_dim;
+    int32_t num_heads;
+    int32_t ff_dim;
+    int32_t esm_dim;
+    int32_t struct_feature_dim;
+    int32_t struct_units;
+    int32_t esm_units1;
+    int32_t esm_units2;
+    int32_t trunk_units1;
+    int32_t trunk_units2;
+    int32_t n_classes;
+} dptm_spec;
+
+typedef struct dptm_handle dptm_handle;
+
+/* Number of fp32 values dptm_create expects for `spec` (1,620,229 for the reference
+ * shape), or a negative error code.  The blob is every weight tensor of
+ * create_ptm_model (model.py:143-210) in the order documented in
+ * deepptmpred_amd/spec.py:tensor_table, each C-contiguous in its Keras shape. */
+int64_t dptm_weight_count(const dptm_spec* spec);
+
+/* Replaces load_model (predict.py:569-577): builds a scorer on GPU `device` from a
+ * host blob of `nbytes` bytes of little-endian fp32 weights. */
+int dptm_create(const void* weights, size_t nbytes, const dptm_spec* spec, int device,
+                dptm_handle** out);
+
+void dptm_destroy(dptm_handle* h);
+
+/* Replaces model.predict([x21, x33, x51, struct, esm]) (predict.py:598-599).  All
+ * pointers are HOST buffers; the call returns after the results are in `out`.
+ *   tok21/tok33/tok51: uint8 [n][21|33|51]; strct: float32 [n][8];
+ *   esm: float32 [n][1280]; out: float32 [n][2].  n = 0 is allowed. */
+int dptm_score(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
+               const float* strct, const float* esm, int64_t n, float* out);
+
+/* Fused form of prepare_protein_data + predict (predict.py:462-485, 598-599): window
+ * assembly and the ESM row gather run on the device.  HOST buffers.
+ *   codes: uint8 [L] residue codes of the protein sequence;
+ *   esm_table: float32 [esm_rows][1280] per-residue table (may be NULL with
+ *              esm_rows = 0: every site then gets a zero row, predict.py:498-500);
+ *              a site whose position-1 >= esm_rows also gets zeros (predict.py:493);
+ *   positions: int32 [n], 1-based; a position outside 1..L fails with DPTM_EINVAL
+ *              (the reference raises IndexError at predict.py:535);
+ *   strct: float32 [n][8]; out: float32 [n][2]. */
+int dptm_score_protein(dptm_handle* h, const uint8_t* codes, int64_t L, const float* esm_table,
+                       int64_t esm_rows, const int32_t* positions, const float* strct, int64_t n,
+                       float* out);
+
+/* Device-resident forms: every pointer is DEVICE memory on the handle's GPU.  The work
+ * is enqueued on `stream` (a hipStream_t passed as void*; NULL = the handle's own
+ * stream) and the call returns without waiting.  These are what the batch scheduler
+ * and bench.py drive; they have no counterpart in the reference, which only ever hands
+ * host arrays to Keras. */
+int dptm_score_device(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33,
+                      const uint8_t* tok51, const float* strct, const float* esm, int64_t n,
+                      float* out, void* stream);
+
+int dptm_score_protein_device(dptm_handle* h, const uint8_t* codes, int64_t L,
+                              const float* esm_table, int64_t esm_rows, const int32_t* positions,
+                              const float* strct, int64_t n, float* out, void* stream);
+
+/* Window assembly alone (predict.py:529-560 on the device).  DEVICE pointers.
+ * Writes tok21/tok33/tok51 uint8 [n][W] and esm_row int32 [n] (= position-1, or -1 when
+ * the site gets a zero ESM row).  Positions must already be validated (1..L). */
+int dptm_assemble_device(dptm_handle* h, const uint8_t* codes, int64_t L, int64_t esm_rows,
+                         const int32_t* positions, int64_t n, uint8_t* tok21, uint8_t* tok33,
+                         uint8_t* tok51, int32_t* esm_row, void* stream);
+
+/* Blocks until everything enqueued on the handle's own stream has finished. */
+int dptm_sync(dptm_handle* h);
+
+/* Per-kernel timing of the device-resident calls, measured with HIP events on the
+ * stream the kernels run on.  dptm_profile_begin arms it; every dptm_score*_device call
+ * after that records events around each kernel launch; dptm_profile_end waits for the
+ * stream, fills `ms` (DPTM_PROF_COUNT floats: total milliseconds per kernel class since
+ * begin) and `launches` (same length: launches per class), and disarms it. */
+enum {
+    DPTM_PROF_ASSEMBLE = 0,
+    DPTM_PROF_BRANCH21 = 1,
+    DPTM_PROF_BRANCH33 = 2,
+    DPTM_PROF_BRANCH51 = 3,
+    DPTM_PROF_STRUCT = 4,
+    DPTM_PROF_ESM1 = 5,
+    DPTM_PROF_ESM2 = 6,
+    DPTM_PROF_TRUNK1 = 7,
+    DPTM_PROF_TRUNK2 = 8,
+    DPTM_PROF_HEAD = 9,
+    DPTM_PROF_COUNT = 10
+};
+int dptm_profile_begin(dptm_handle* h);
+int dptm_profile_end(dptm_handle* h, float* ms, int64_t* launches);
+
+/* Largest number of sites the device-resident calls process per internal pass. */
+int64_t dptm_chunk_sites(const dptm_handle* h);
+
+const char* dptm_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPTM_H */

@@ -1,0 +1,75 @@
+"""The C-ABI library loads and exports every entry point include/dptm.h declares
+(no compute: this runs without a GPU), and the host-side wrapper validates inputs."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from deepptmpred_amd import _native, spec
+from deepptmpred_amd.model import Model, create_ptm_model, encode_sequence, load_model
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dptm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dptm_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    lib = _native.load_library()
+    names = declared_symbols()
+    assert "dptm_create" in names and "dptm_score" in names and "dptm_score_protein" in names
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in dptm.h but not exported"
+    assert sorted(_native.EXPORTS) == names
+
+
+def test_weight_count_matches_spec():
+    lib = _native.load_library()
+    cs = _native.DptmSpec.from_spec(spec.DEFAULT_SPEC)
+    assert lib.dptm_weight_count(cs) == spec.n_params()
+    bad = _native.DptmSpec.from_spec(spec.ModelSpec(embed_dim=32))
+    assert lib.dptm_weight_count(bad) < 0
+    assert b"unsupported" in lib.dptm_last_error()
+
+
+def test_predict_validates_inputs_without_gpu():
+    m = create_ptm_model(seed=1)
+    x = spec.synthetic_inputs(4, 1)
+    with pytest.raises(ValueError):
+        m.predict(x[:4])
+    bad = list(x)
+    bad[0] = bad[0][:, :20]
+    with pytest.raises(ValueError):
+        m.predict(bad)
+    bad = list(x)
+    bad[1] = bad[1].astype(np.int64) + 30
+    with pytest.raises(ValueError):
+        m.predict(bad)
+    empty = [a[:0] for a in x]
+    out = m.predict(empty)
+    assert out.shape == (0, 2) and out.dtype == np.float32
+    with pytest.raises(IndexError):
+        m.predict_protein("ACDK", [5], np.zeros((1, 8)))
+
+
+def test_encode_sequence_table():
+    assert encode_sequence("ACDEFGHIKLMNPQRSTVWY*XB").tolist() == list(range(21)) + [20, 20]
+
+
+def test_model_weights_roundtrip(tmp_path):
+    m = create_ptm_model(seed=3)
+    ws = m.get_weights()
+    assert len(ws) == len(spec.tensor_table()) and sum(w.size for w in ws) == spec.n_params()
+    p = tmp_path / "w.dptm"
+    m.save(str(p))
+    m2 = load_model(str(p), custom_objects={"PositionEmbedding": object}, compile=False)
+    for a, b in zip(ws, m2.get_weights()):
+        assert np.array_equal(a, b)
+    with pytest.raises(OSError):
+        load_model(str(tmp_path / "missing.h5"))
+    with pytest.raises(ValueError):
+        m.set_weights(ws[:-1])

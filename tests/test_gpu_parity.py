@@ -1,0 +1,171 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  fp32 bound from the
+task statement: probabilities within 1e-4 absolute of the reference CPU model."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from deepptmpred_amd import spec
+from deepptmpred_amd.model import Model, encode_sequence
+from oracle import ptm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4  # absolute, on probabilities (fp32 path)
+
+
+@pytest.fixture(scope="module")
+def weights():
+    return spec.synthetic_weights(7)
+
+
+@pytest.fixture(scope="module")
+def model(weights):
+    m = Model(weights)
+    yield m
+    m.close()
+
+
+def oracle(weights, x):
+    with np.errstate(over="ignore"):
+        return O.forward(weights, x, np.float64)
+
+
+def test_golden_fixture(model, golden_dir):
+    g = np.load(os.path.join(golden_dir, "synthetic_s7.npz"))
+    x = [g["tok21"], g["tok33"], g["tok51"], g["struct"], g["esm"]]
+    p = model.predict(x)
+    assert p.shape == (64, 2) and p.dtype == np.float32
+    err = np.abs(p.astype(np.float64) - g["proba"]).max()
+    print("golden max abs err", err)
+    assert err < TOL
+    # identical thresholded calls (predict.py:609) away from the threshold
+    far = np.abs(g["proba"][:, 1] - 0.5) > 1e-3
+    assert np.array_equal((p[:, 1] >= 0.5)[far], (g["proba"][:, 1] >= 0.5)[far])
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 7, 12, 13, 64, 257, 1000])
+def test_ragged_sizes_vs_oracle(model, weights, n):
+    x = spec.synthetic_inputs(n, 1000 + n)
+    p = model.predict(x)
+    ref = oracle(weights, x)
+    assert np.abs(p - ref).max() < TOL
+    assert np.allclose(p.sum(axis=1), 1.0, atol=1e-6)
+
+
+def test_input_dtypes(model, weights):
+    x = spec.synthetic_inputs(33, 3)
+    ref = oracle(weights, x)
+    y = [x[0].astype(np.int64), x[1].astype(np.float32), x[2].astype(np.int32),
+         x[3].astype(np.float64), x[4].astype(np.float64)]
+    assert np.abs(model.predict(y, batch_size=128, verbose=0) - ref).max() < TOL
+    assert model.predict([a[:0] for a in x]).shape == (0, 2)
+
+
+@pytest.mark.parametrize("seed", [100, 101])
+def test_other_weight_sets(seed):
+    w = spec.synthetic_weights(seed)
+    m = Model(w)
+    x = spec.synthetic_inputs(200, seed)
+    assert np.abs(m.predict(x) - oracle(w, x)).max() < TOL
+    m.close()
+
+
+def test_all_padding_and_edges(model, weights):
+    x = spec.synthetic_inputs(16, 8)
+    x[0][:] = 20; x[1][:] = 20; x[2][:] = 20           # every window entirely '*'
+    x[3][:] = np.array([0.5, 0, 0, 0, 1, 0, 85, 85], dtype=np.float32)   # predict.py:526
+    x[4][:8] = 0.0                                      # missing-ESM rows (predict.py:500)
+    assert np.abs(model.predict(x) - oracle(weights, x)).max() < TOL
+
+
+def test_rows_independent_and_ordered(model):
+    """Size-independent properties: scoring is per site, so any permutation or split of the
+    batch gives the same rows; covers the multi-pass path (n > one internal pass)."""
+    n = model.scorer.chunk_sites + 1000
+    x = spec.synthetic_inputs(n, 77)
+    p = model.predict(x)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(n)
+    q = model.predict([a[perm] for a in x])
+    assert np.array_equal(q, p[perm])
+    head = model.predict([a[:777] for a in x])
+    assert np.array_equal(head, p[:777])
+    tail = model.predict([a[-1000:] for a in x])
+    assert np.array_equal(tail, p[-1000:])
+    assert np.isfinite(p).all() and np.abs(p.sum(axis=1) - 1).max() < 1e-6
+
+
+@pytest.mark.parametrize("pid,tag", [("P31749", "phospho"), ("P31749", "ubiq"), ("P10636", "phospho")])
+def test_shipped_proteins(model, weights, golden_dir, pid, tag):
+    g = np.load(os.path.join(golden_dir, "proteins.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "proteins.json")))[pid]
+    seq = meta["sequence"]
+    pos = g[f"{pid}_{tag}_positions"]
+    esm = g[f"{pid}_{tag}_esm"]
+    toks = [g[f"{pid}_{tag}_tok{w}"] for w in (21, 33, 51)]
+    st = np.tile(O.DEFAULT_STRUCT_ROW, (len(pos), 1))
+    ref = oracle(weights, toks + [st, esm])
+    # (1) pre-assembled inputs through predict
+    p1 = model.predict(toks + [st, esm])
+    assert np.abs(p1 - ref).max() < TOL
+    # (2) raw sequence: windows and the ESM gather on the device
+    table = np.zeros((meta["esm_rows"], 1280), dtype=np.float32)
+    table[pos - 1] = esm
+    p2 = model.predict_protein(seq, pos, st, table)
+    assert np.abs(p2 - ref).max() < TOL
+    assert np.array_equal(p1, p2)
+    # a table shorter than the protein: sites past its end get zero rows (predict.py:493)
+    short = table[:300]
+    esm0 = esm.copy()
+    esm0[pos - 1 >= 300] = 0
+    p3 = model.predict_protein(seq, pos, st, short)
+    assert np.abs(p3 - oracle(weights, toks + [st, esm0])).max() < TOL
+    # no table at all
+    p4 = model.predict_protein(seq, pos, st, None)
+    assert np.abs(p4 - oracle(weights, toks + [st, np.zeros_like(esm)])).max() < TOL
+
+
+def test_assemble_bit_exact(model, golden_dir):
+    import torch
+    meta = json.load(open(os.path.join(golden_dir, "proteins.json")))
+    dev = torch.device("cuda:0")
+    for pid in ("P31749", "P10636"):
+        seq = meta[pid]["sequence"]
+        L = len(seq)
+        pos = np.arange(1, L + 1, dtype=np.int32)            # every residue, incl. both ends
+        want = [O.encode_sequences(O.get_sequence_windows(seq, pos.tolist(), w)) for w in (21, 33, 51)]
+        codes = torch.from_numpy(encode_sequence(seq)).to(dev)
+        dpos = torch.from_numpy(pos).to(dev)
+        toks = [torch.empty((L, w), dtype=torch.uint8, device=dev) for w in (21, 33, 51)]
+        rows = torch.empty(L, dtype=torch.int32, device=dev)
+        model.scorer.assemble_device(codes.data_ptr(), L, L - 10, dpos.data_ptr(), L, toks[0].data_ptr(),
+                                     toks[1].data_ptr(), toks[2].data_ptr(), rows.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for t, w in zip(toks, want):
+            assert np.array_equal(t.cpu().numpy(), w.astype(np.uint8))
+        r = rows.cpu().numpy()
+        assert np.array_equal(r[: L - 10], np.arange(L - 10)) and (r[L - 10:] == -1).all()
+
+
+def test_device_entry_matches_host_entry(model):
+    import torch
+    dev = torch.device("cuda:0")
+    x = spec.synthetic_inputs(3000, 21)
+    host = model.predict(x)
+    d = [torch.from_numpy(a).to(dev) for a in x]
+    out = torch.empty((3000, 2), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    model.scorer.score_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
+                              d[4].data_ptr(), 3000, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), host)
+
+
+def test_bad_position_is_rejected(model):
+    with pytest.raises(IndexError):
+        model.predict_protein("ACDEFGHIK", [0], np.zeros((1, 8)))
+    with pytest.raises(IndexError):
+        model.predict_protein("ACDEFGHIK", [10], np.zeros((1, 8)))
