@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""Throughput of the scoring path on MI355X: sites ("windows") scored per second.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--sites S]
+
+Workload (BASELINE.json config 3): S = 1,000,000 synthetic sites per GPU -- three token
+windows (21/33/51 residues), one 1280-float ESM-2 row and 8 structure features each --
+resident in HBM before the timed region; one "step" scores all of them once in fp32
+through the C ABI (dptm_score_device).  For N > 1 every rank scores its own S sites
+(sites are independent: no data-path collective), so scaling is weak and `value` is the
+whole-job rate.  Rank 0 prints ONE JSON line.
+
+Also reported on the same line:
+  roofline     the dominant kernel (fused W=51 sequence branch): algorithmic FLOPs per
+               launch / its average launch time, measured with HIP events on the launch
+               stream in an extra profiled step, against the dense fp32 MFMA peak.
+  cpu_baseline the torch-CPU restatement of the reference graph (oracle/torch_ref.py)
+               timed on a bounded sample of the same workload on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FLOPS_PER_SITE = 31_234_816          # 2*MAC of every contraction of the forward graph
+FLOPS_BRANCH = {21: 5_564_160, 33: 8_946_432, 51: 14_296_320}
+BYTES_PER_SITE = 5_261               # 1280*4 + 8*4 + 105 + 4
+PEAK_F32_MFMA_TFLOPS = 157.3         # dense fp32 matrix peak of MI355X
+PEAK_HBM_GBS = 8000.0
+
+
+def device_inputs(n: int, seed: int, dev: torch.device):
+    """Same distributions as deepptmpred_amd.spec.synthetic_inputs, generated on the GPU."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    wide = torch.randint(0, 20, (n, 51), generator=g, device=dev, dtype=torch.uint8)
+    padded = torch.rand(n, generator=g, device=dev) < 0.05
+    side = torch.randint(0, 2, (n,), generator=g, device=dev)
+    plen = torch.randint(1, 26, (n,), generator=g, device=dev)
+    col = torch.arange(51, device=dev)[None, :]
+    left = padded[:, None] & (side[:, None] == 0) & (col < plen[:, None])
+    right = padded[:, None] & (side[:, None] == 1) & (col >= 51 - plen[:, None])
+    wide[left | right] = 20
+    toks = [wide[:, 25 - h:25 + h + 1].contiguous() for h in (10, 16, 25)]
+    del left, right
+    esm = torch.empty((n, 1280), device=dev, dtype=torch.float32)
+    step = 1 << 17
+    for s in range(0, n, step):   # chunked: keeps the temporaries small
+        e = min(n, s + step)
+        blk = torch.randn((e - s, 1280), generator=g, device=dev) * 0.27
+        heavy = torch.rand((e - s, 1280), generator=g, device=dev) < 0.01
+        esm[s:e] = torch.where(heavy, blk * 10.0, blk)
+    st = torch.zeros((n, 8), device=dev, dtype=torch.float32)
+    st[:, 0] = torch.rand(n, generator=g, device=dev) * 250
+    st[:, 1] = torch.rand(n, generator=g, device=dev) * 360 - 180
+    st[:, 2] = torch.rand(n, generator=g, device=dev) * 360 - 180
+    ss = torch.randint(0, 3, (n,), generator=g, device=dev)
+    st[torch.arange(n, device=dev), 3 + ss] = 1.0
+    st[:, 6] = torch.rand(n, generator=g, device=dev) * 80 + 20
+    st[:, 7] = torch.rand(n, generator=g, device=dev) * 80 + 20
+    return toks + [st, esm]
+
+
+def cpu_baseline(weights, budget_s: float = 15.0):
+    """Times oracle/torch_ref.py (fp32, batch 4096) on the host cores for ~budget_s."""
+    from deepptmpred_amd import spec
+    from oracle.torch_ref import TorchRef
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    ref = TorchRef(weights, torch.float32)
+    probe = spec.synthetic_inputs(1024, 5)
+    ref.predict(probe, batch_size=1024)          # warm-up
+    t0 = time.perf_counter()
+    ref.predict(probe, batch_size=1024)
+    per_site = (time.perf_counter() - t0) / 1024
+    n = int(min(max(budget_s / max(per_site, 1e-9), 2048), 65536))
+    n = (n // 1024) * 1024
+    x = spec.synthetic_inputs(n, 6)
+    t0 = time.perf_counter()
+    ref.predict(x, batch_size=4096)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "sites/s", "cores": threads, "kind": "port",
+            "sample": f"{n} synthetic sites, torch-CPU fp32 restatement, batch 4096, {dt:.1f} s"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--sites", type=int, default=1_000_000, help="sites per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device(f"cuda:{local}"))
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+
+    from deepptmpred_amd import spec
+    from deepptmpred_amd.model import Model
+
+    weights = spec.synthetic_weights(7)
+    model = Model(weights, device=local)
+    sc = model.scorer
+    n = args.sites
+    x = device_inputs(n, 1234 + rank, dev)
+    out = torch.empty((n, 2), device=dev, dtype=torch.float32)
+    stream = torch.cuda.current_stream().cuda_stream
+    ptrs = [t.data_ptr() for t in x]
+
+    def step():
+        sc.score_device(ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], n, out.data_ptr(), stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: finite probabilities that sum to one
+    chk = out[:: max(1, n // 4096)].cpu().numpy()
+    assert np.isfinite(chk).all() and np.abs(chk.sum(axis=1) - 1).max() < 1e-5
+
+    # one extra, profiled step: per-kernel HIP-event timings on the launch stream
+    sc.profile_begin()
+    step()
+    prof = sc.profile_end()
+    barrier()
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = world * n * args.steps / elapsed
+        b51_ms, b51_launches = prof["branch51"]
+        sites_per_launch = n / max(b51_launches, 1)
+        avg_s = b51_ms * 1e-3 / max(b51_launches, 1)
+        achieved = sites_per_launch * FLOPS_BRANCH[51] / avg_s / 1e12 if avg_s > 0 else 0.0
+        total_kernel_ms = sum(v[0] for v in prof.values())
+        line = {
+            "metric": "windows scored/sec", "value": value, "unit": "sites/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (device-generated sites, seeded synthetic weights)",
+            "config": {"workload": "config 3: 1M synthetic sites (windows 21/33/51 + ESM-2 1280 + 8 struct), fp32, 1 MI355X",
+                       "sites_per_gpu": n, "parallelism": f"dp{world} (sites sharded, no collective)"},
+            "roofline": {"bound": "mfma", "kernel": "branch_kernel<51>", "achieved": achieved,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "avg_launch_ms": avg_s * 1e3, "sites_per_launch": sites_per_launch,
+                         "flops_per_site": FLOPS_BRANCH[51]},
+            "whole_path": {"tflops": value / world * FLOPS_PER_SITE / 1e12,
+                           "frac_of_f32_mfma_peak": value / world * FLOPS_PER_SITE / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                           "hbm_gbs_algorithmic": value / world * BYTES_PER_SITE / 1e9,
+                           "frac_of_hbm_peak": value / world * BYTES_PER_SITE / 1e9 / PEAK_HBM_GBS},
+            "kernel_ms_per_step": {k: round(v[0], 3) for k, v in prof.items()},
+            "kernel_ms_total": round(total_kernel_ms, 3),
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(weights)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
