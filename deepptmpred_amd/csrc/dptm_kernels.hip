@@ -53,19 +53,29 @@ __device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[NT], const f32x4* __
         }
 }
 
-// acc[t] += W^T-tile(t) * X^T with X held in registers (chain layout, K8 groups of 8 feats)
-template <int K8, int NT>
+// acc[t] += W^T-tile(t) * X^T with X held in registers (chain layout, K8 groups of 8 feats).
+// Weight fragments are fetched DIST groups ahead of the MFMAs that consume them; the
+// sched_barrier at the end of every group pins that order so the L2 latency of a fetch is
+// covered by the 4*NT*DIST MFMAs issued after it.
+template <int K8, int NT, int DIST = 2>
 __device__ __forceinline__ void gemm_regs(f32x16 (&acc)[NT], const f32x4* __restrict__ wp,
                                           const f32x4 (&x)[K8], int lane) {
+    f32x4 a[K8][NT];
+#pragma unroll
+    for (int u = 0; u < DIST && u < K8; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[u][t] = wp[(t * K8 + u) * 64 + lane];
 #pragma unroll
     for (int u = 0; u < K8; ++u) {
-        f32x4 a[NT];
+        if (u + DIST < K8) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) a[t] = wp[(t * K8 + u) * 64 + lane];
+            for (int t = 0; t < NT; ++t) a[u + DIST][t] = wp[(t * K8 + u + DIST) * 64 + lane];
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) mfma(acc[t], a[t][e], x[u][e]);
+            for (int t = 0; t < NT; ++t) mfma(acc[t], a[u][t][e], x[u][e]);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -177,30 +187,37 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
         const float* xr = tap2_ok ? xc + kLdsStride : xc;
         const f32x4* wsc = P + kOffScW;
         const f32x4* wa = P + kOffC3aW;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const f32x4 bc = *reinterpret_cast<const f32x4*>(xc + 8 * u);
-            f32x4 bl = *reinterpret_cast<const f32x4*>(xl + 8 * u);
-            f32x4 br = *reinterpret_cast<const f32x4*>(xr + 8 * u);
-            if (!tap0_ok) bl = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (!tap2_ok) br = f32x4{0.f, 0.f, 0.f, 0.f};
-            f32x4 a_sc[2], a0[2], a1[2], a2[2];
+        f32x4 a_sc[2][2], a0[2][2], a1[2][2], a2[2][2];  // [parity of u][out tile]
+        f32x4 bc[2], bl[2], br[2];
+        auto fetch_a = [&](int u, int s) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                a_sc[t] = wsc[(t * 8 + u) * 64 + lane];
-                a0[t] = wa[0 * kMat64 + (t * 8 + u) * 64 + lane];
-                a1[t] = wa[1 * kMat64 + (t * 8 + u) * 64 + lane];
-                a2[t] = wa[2 * kMat64 + (t * 8 + u) * 64 + lane];
+                a_sc[s][t] = wsc[(t * 8 + u) * 64 + lane];
+                a0[s][t] = wa[0 * kMat64 + (t * 8 + u) * 64 + lane];
+                a1[s][t] = wa[1 * kMat64 + (t * 8 + u) * 64 + lane];
+                a2[s][t] = wa[2 * kMat64 + (t * 8 + u) * 64 + lane];
             }
+            bc[s] = *reinterpret_cast<const f32x4*>(xc + 8 * u);
+            bl[s] = *reinterpret_cast<const f32x4*>(xl + 8 * u);
+            br[s] = *reinterpret_cast<const f32x4*>(xr + 8 * u);
+        };
+        fetch_a(0, 0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int s = u & 1;
+            if (u + 1 < 8) fetch_a(u + 1, s ^ 1);
+            if (!tap0_ok) bl[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!tap2_ok) br[s] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    mfma(acc_s[t], a_sc[t][e], bc[e]);
-                    mfma(acc_a[t], a0[t][e], bl[e]);
-                    mfma(acc_a[t], a1[t][e], bc[e]);
-                    mfma(acc_a[t], a2[t][e], br[e]);
+                    mfma(acc_s[t], a_sc[s][t][e], bc[s][e]);
+                    mfma(acc_a[t], a0[s][t][e], bl[s][e]);
+                    mfma(acc_a[t], a1[s][t][e], bc[s][e]);
+                    mfma(acc_a[t], a2[s][t][e], br[s][e]);
                 }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // y1 = BN1(swish(conv3a)) -> bufB (own rows)
         f32x4 y[8];
@@ -221,27 +238,33 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
         const float* yl = tap0_ok ? yc - kLdsStride : yc;
         const float* yr = tap2_ok ? yc + kLdsStride : yc;
         const f32x4* wb = P + kOffC3bW;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            f32x4 bl = *reinterpret_cast<const f32x4*>(yl + 8 * u);
-            f32x4 br = *reinterpret_cast<const f32x4*>(yr + 8 * u);
-            if (!tap0_ok) bl = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (!tap2_ok) br = f32x4{0.f, 0.f, 0.f, 0.f};
-            f32x4 a0[2], a1[2], a2[2];
+        f32x4 c0[2][2], c1[2][2], c2[2][2], dl[2], dr[2];
+        auto fetch_b = [&](int u, int s) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                a0[t] = wb[0 * kMat64 + (t * 8 + u) * 64 + lane];
-                a1[t] = wb[1 * kMat64 + (t * 8 + u) * 64 + lane];
-                a2[t] = wb[2 * kMat64 + (t * 8 + u) * 64 + lane];
+                c0[s][t] = wb[0 * kMat64 + (t * 8 + u) * 64 + lane];
+                c1[s][t] = wb[1 * kMat64 + (t * 8 + u) * 64 + lane];
+                c2[s][t] = wb[2 * kMat64 + (t * 8 + u) * 64 + lane];
             }
+            dl[s] = *reinterpret_cast<const f32x4*>(yl + 8 * u);
+            dr[s] = *reinterpret_cast<const f32x4*>(yr + 8 * u);
+        };
+        fetch_b(0, 0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int s = u & 1;
+            if (u + 1 < 8) fetch_b(u + 1, s ^ 1);
+            if (!tap0_ok) dl[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!tap2_ok) dr[s] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    mfma(acc_b[t], a0[t][e], bl[e]);
-                    mfma(acc_b[t], a1[t][e], y[u][e]);
-                    mfma(acc_b[t], a2[t][e], br[e]);
+                    mfma(acc_b[t], c0[s][t][e], dl[s][e]);
+                    mfma(acc_b[t], c1[s][t][e], y[u][e]);
+                    mfma(acc_b[t], c2[s][t][e], dr[s][e]);
                 }
+            __builtin_amdgcn_sched_barrier(0);
         }
         f32x4 s[8];
         acc_to_x<2>(acc_b, x1);
@@ -380,7 +403,7 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
                 f32x16 acc_h[4];
                 // hidden tiles 4c..4c+3 <-> bias groups 16c..16c+15 of the 256-vector
                 acc_init_bias<4>(acc_h, T + kTbB1 + 16 * c, h, 32);
-                gemm_regs<8, 4>(acc_h, T + kTbF1 + (4 * c) * 8 * 64, hres, lane);
+                gemm_regs<8, 4, 1>(acc_h, T + kTbF1 + (4 * c) * 8 * 64, hres, lane);
                 f32x4 hid[16];
                 acc_to_x<4>(acc_h, hid);
 #pragma unroll
@@ -388,15 +411,25 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
 #pragma unroll
                     for (int e = 0; e < 4; ++e) hid[u][e] = swishf(hid[u][e]);
                 // second layer: K = 256 -> 32 groups per out tile; this half is groups 16c..
+                {
+                    f32x4 a[16][2];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    f32x4 a[2];
+                    for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) a[t] = T[kTbF2 + (t * 32 + 16 * c + u) * 64 + lane];
+                        for (int t = 0; t < 2; ++t) a[u][t] = T[kTbF2 + (t * 32 + 16 * c + u) * 64 + lane];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                    for (int u = 0; u < 16; ++u) {
+                        if (u + 2 < 16) {
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) mfma(acc_o[t], a[t][e], hid[u][e]);
+                            for (int t = 0; t < 2; ++t)
+                                a[u + 2][t] = T[kTbF2 + (t * 32 + 16 * c + u + 2) * 64 + lane];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int t = 0; t < 2; ++t) mfma(acc_o[t], a[u][t][e], hid[u][e]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
             acc_to_x<2>(acc_o, x1);
