@@ -14,7 +14,8 @@ import numpy as np
 from .spec import DEFAULT_SPEC, ModelSpec
 
 _LIB_NAME = "libdptm.so"
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+# DPTM_LIBRARY overrides the in-tree path (used to A/B kernel builds); still the same C ABI
+_LIB_PATH = os.environ.get("DPTM_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 
 DPTM_OK, DPTM_EINVAL, DPTM_EHIP, DPTM_ENOMEM = 0, -1, -2, -3
 PROF_NAMES = ("assemble", "branch21", "branch33", "branch51", "struct", "esm1", "esm2",

@@ -14,6 +14,9 @@
 
 #include "dptm_layout.h"
 #include "dptm_kernels.h"
+#ifndef ABL_HEADS
+#define ABL_HEADS 2
+#endif
 
 namespace dptm {
 
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
         // attention: this lane = (query row, two heads).  After the regrouping,
         // qa[4u+e] / qb[4u+e] hold features 32h + 8u + e / 32h + 8u + 4 + e.
 #pragma unroll
-        for (int hd = 0; hd < 2; ++hd) {
+        for (int hd = 0; hd < ABL_HEADS; ++hd) {
             const float* kp = bufA + row_start * kLdsStride + 32 * h + 16 * hd;
             const float* vp = bufB + row_start * kLdsStride + 32 * h + 16 * hd;
             float sc[W];
