@@ -325,50 +325,54 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
         __syncthreads();  // K and V of the whole tile are in LDS
         // attention: this lane = (query row, two heads).  After the regrouping,
         // qa[4u+e] / qb[4u+e] hold features 32h + 8u + e / 32h + 8u + 4 + e.
+        // Keys are walked in three chunks of W/3 with a running maximum (the usual
+        // rescaling form of softmax), which keeps only W/3 scores live per lane.
 #pragma unroll
         for (int hd = 0; hd < ABL_HEADS; ++hd) {
+            constexpr int CH = W / 3;
+            static_assert(CH * 3 == W, "window sizes are multiples of 3");
             const float* kp = bufA + row_start * kLdsStride + 32 * h + 16 * hd;
             const float* vp = bufB + row_start * kLdsStride + 32 * h + 16 * hd;
-            float sc[W];
-            float m = -3.0e38f;
+            float m = -3.0e38f, den = 0.f;
+            f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0, o2 = o0, o3 = o0;
+#pragma unroll 1
+            for (int c = 0; c < 3; ++c) {
+                float sc[CH];
+                float cm = -3.0e38f;
 #pragma unroll
-            for (int t = 0; t < W; ++t) {
-                const f32x4 k0 = *reinterpret_cast<const f32x4*>(kp + t * kLdsStride);
-                const f32x4 k1 = *reinterpret_cast<const f32x4*>(kp + t * kLdsStride + 4);
-                const f32x4 k2 = *reinterpret_cast<const f32x4*>(kp + t * kLdsStride + 8);
-                const f32x4 k3 = *reinterpret_cast<const f32x4*>(kp + t * kLdsStride + 12);
-                float a = 0.f;
+                for (int t = 0; t < CH; ++t) {
+                    const f32x4 k0 = *reinterpret_cast<const f32x4*>(kp + t * kLdsStride);
+                    const f32x4 k1 = *reinterpret_cast<const f32x4*>(kp + t * kLdsStride + 4);
+                    const f32x4 k2 = *reinterpret_cast<const f32x4*>(kp + t * kLdsStride + 8);
+                    const f32x4 k3 = *reinterpret_cast<const f32x4*>(kp + t * kLdsStride + 12);
+                    float a = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    a = fmaf(qa[8 * hd + e], k0[e], a);
-                    a = fmaf(qb[8 * hd + e], k1[e], a);
-                    a = fmaf(qa[8 * hd + 4 + e], k2[e], a);
-                    a = fmaf(qb[8 * hd + 4 + e], k3[e], a);
+                    for (int e = 0; e < 4; ++e) {
+                        a = fmaf(qa[8 * hd + e], k0[e], a);
+                        a = fmaf(qb[8 * hd + e], k1[e], a);
+                        a = fmaf(qa[8 * hd + 4 + e], k2[e], a);
+                        a = fmaf(qb[8 * hd + 4 + e], k3[e], a);
+                    }
+                    sc[t] = a;
+                    cm = fmaxf(cm, a);
                 }
-                sc[t] = a;
-                m = fmaxf(m, a);
-            }
-            float den = 0.f;
+                const float mn = fmaxf(m, cm);
+                const float alpha = __expf(m - mn);
+                m = mn;
+                den *= alpha;
+                o0 *= alpha; o1 *= alpha; o2 *= alpha; o3 *= alpha;
 #pragma unroll
-            for (int t = 0; t < W; ++t) {
-                sc[t] = __expf(sc[t] - m);
-                den += sc[t];
-            }
-            float o0[4] = {0.f, 0.f, 0.f, 0.f}, o1[4] = {0.f, 0.f, 0.f, 0.f};
-            float o2[4] = {0.f, 0.f, 0.f, 0.f}, o3[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < W; ++t) {
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(vp + t * kLdsStride);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(vp + t * kLdsStride + 4);
-                const f32x4 v2 = *reinterpret_cast<const f32x4*>(vp + t * kLdsStride + 8);
-                const f32x4 v3 = *reinterpret_cast<const f32x4*>(vp + t * kLdsStride + 12);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    o0[e] = fmaf(sc[t], v0[e], o0[e]);
-                    o1[e] = fmaf(sc[t], v1[e], o1[e]);
-                    o2[e] = fmaf(sc[t], v2[e], o2[e]);
-                    o3[e] = fmaf(sc[t], v3[e], o3[e]);
+                for (int t = 0; t < CH; ++t) {
+                    const float pr = __expf(sc[t] - mn);
+                    den += pr;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(vp + t * kLdsStride);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(vp + t * kLdsStride + 4);
+                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(vp + t * kLdsStride + 8);
+                    const f32x4 v3 = *reinterpret_cast<const f32x4*>(vp + t * kLdsStride + 12);
+                    o0 += pr * v0; o1 += pr * v1; o2 += pr * v2; o3 += pr * v3;
                 }
+                kp += CH * kLdsStride;
+                vp += CH * kLdsStride;
             }
             const float rden = 1.0f / den;
 #pragma unroll
