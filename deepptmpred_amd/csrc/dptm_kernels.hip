@@ -406,30 +406,30 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
             f32x16 acc_o[2];
             acc_init_bias<2>(acc_o, tv + kVB2 * kVec64, h, 8);
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                f32x16 acc_h[4];
-                // hidden tiles 4c..4c+3 <-> bias groups 16c..16c+15 of the 256-vector
-                acc_init_bias<4>(acc_h, T + kTbB1 + 16 * c, h, 32);
-                gemm_regs<8, 4, 1>(acc_h, T + kTbF1 + (4 * c) * 8 * 64, hres, lane);
-                f32x4 hid[16];
-                acc_to_x<4>(acc_h, hid);
+            for (int c = 0; c < 4; ++c) {
+                f32x16 acc_h[2];
+                // hidden tiles 2c, 2c+1 <-> bias groups 8c..8c+7 of the 256-vector
+                acc_init_bias<2>(acc_h, T + kTbB1 + 8 * c, h, 32);
+                gemm_regs<8, 2, 2>(acc_h, T + kTbF1 + (2 * c) * 8 * 64, hres, lane);
+                f32x4 hid[8];
+                acc_to_x<2>(acc_h, hid);
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
+                for (int u = 0; u < 8; ++u)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) hid[u][e] = swishf(hid[u][e]);
-                // second layer: K = 256 -> 32 groups per out tile; this half is groups 16c..
+                // second layer: K = 256 -> 32 groups per out tile; this quarter is groups 8c..
                 {
-                    f32x4 a[16][2];
+                    f32x4 a[8][2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) a[u][t] = T[kTbF2 + (t * 32 + 16 * c + u) * 64 + lane];
+                        for (int t = 0; t < 2; ++t) a[u][t] = T[kTbF2 + (t * 32 + 8 * c + u) * 64 + lane];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        if (u + 2 < 16) {
+                    for (int u = 0; u < 8; ++u) {
+                        if (u + 2 < 8) {
 #pragma unroll
                             for (int t = 0; t < 2; ++t)
-                                a[u + 2][t] = T[kTbF2 + (t * 32 + 16 * c + u + 2) * 64 + lane];
+                                a[u + 2][t] = T[kTbF2 + (t * 32 + 8 * c + u + 2) * 64 + lane];
                         }
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
