@@ -25,6 +25,10 @@ EXPORTS = (
     "dptm_weight_count", "dptm_create", "dptm_destroy", "dptm_score", "dptm_score_protein",
     "dptm_score_device", "dptm_score_protein_device", "dptm_assemble_device", "dptm_sync",
     "dptm_profile_begin", "dptm_profile_end", "dptm_chunk_sites", "dptm_last_error",
+    "dptm_trainer_create", "dptm_trainer_destroy", "dptm_trainer_forward_backward",
+    "dptm_trainer_grad_buffer", "dptm_trainer_param_floats", "dptm_trainer_apply",
+    "dptm_trainer_get_weights", "dptm_trainer_get_grads", "dptm_trainer_get_proba",
+    "dptm_trainer_last_error",
 )
 
 
@@ -60,6 +64,14 @@ class DptmSpec(C.Structure):
         s.trunk_units2 = spec.trunk_units2
         s.n_classes = spec.n_classes
         return s
+
+
+class TrainOpts(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint32), ("rate_embed", C.c_float), ("rate_conv", C.c_float),
+        ("rate_tb", C.c_float), ("rate_dense", C.c_float), ("n_global", C.c_int64),
+        ("n_pos_global", C.c_int64), ("l2", C.c_float), ("l2_scale", C.c_float),
+    ]
 
 
 _lib: Optional[C.CDLL] = None
@@ -112,6 +124,26 @@ def load_library() -> C.CDLL:
     lib.dptm_chunk_sites.argtypes = [vp]
     lib.dptm_last_error.restype = C.c_char_p
     lib.dptm_last_error.argtypes = []
+    lib.dptm_trainer_create.restype = C.c_int
+    lib.dptm_trainer_create.argtypes = [vp, C.c_size_t, C.POINTER(DptmSpec), C.c_int, i64, C.POINTER(vp)]
+    lib.dptm_trainer_destroy.restype = None
+    lib.dptm_trainer_destroy.argtypes = [vp]
+    lib.dptm_trainer_forward_backward.restype = C.c_int
+    lib.dptm_trainer_forward_backward.argtypes = [vp, u8p, u8p, u8p, f32p, f32p, i32p, i64,
+                                                  C.POINTER(TrainOpts), C.POINTER(C.c_float), vp]
+    lib.dptm_trainer_grad_buffer.restype = C.c_int
+    lib.dptm_trainer_grad_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+    lib.dptm_trainer_param_floats.restype = C.c_int64
+    lib.dptm_trainer_param_floats.argtypes = [vp]
+    lib.dptm_trainer_apply.restype = C.c_int
+    lib.dptm_trainer_apply.argtypes = [vp, C.c_float, C.c_float, C.c_float, vp]
+    for name in ("dptm_trainer_get_weights", "dptm_trainer_get_grads"):
+        getattr(lib, name).restype = C.c_int
+        getattr(lib, name).argtypes = [vp, f32p]
+    lib.dptm_trainer_get_proba.restype = C.c_int
+    lib.dptm_trainer_get_proba.argtypes = [vp, f32p, i64]
+    lib.dptm_trainer_last_error.restype = C.c_char_p
+    lib.dptm_trainer_last_error.argtypes = []
     _lib = lib
     return lib
 
@@ -207,3 +239,76 @@ class Scorer:
         cnt = np.zeros(len(PROF_NAMES), dtype=np.int64)
         _check(self._lib, self._lib.dptm_profile_end(self._h, _ptr(ms), _ptr(cnt)), "dptm_profile_end")
         return {k: (float(m), int(c)) for k, m, c in zip(PROF_NAMES, ms, cnt)}
+
+
+def _check_t(lib, rc: int, what: str) -> None:
+    if rc == DPTM_OK:
+        return
+    msg = (lib.dptm_trainer_last_error() or lib.dptm_last_error() or b"").decode("utf-8", "replace")
+    if rc == DPTM_EINVAL:
+        raise ValueError(f"{what}: {msg}")
+    if rc == DPTM_ENOMEM:
+        raise MemoryError(f"{what}: {msg}")
+    raise RuntimeError(f"{what}: {msg}")
+
+
+class Trainer:
+    """One ``dptm_trainer``: a trainable replica on one GPU (device-pointer interface)."""
+
+    def __init__(self, blob: np.ndarray, spec: ModelSpec = DEFAULT_SPEC, device: int = 0,
+                 max_batch: int = 64):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.spec = spec
+        self.n_canonical = int(np.asarray(blob).size)
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        cs = DptmSpec.from_spec(spec)
+        rc = self._lib.dptm_trainer_create(_ptr(blob), blob.nbytes, C.byref(cs), device, max_batch,
+                                           C.byref(self._h))
+        _check_t(self._lib, rc, "dptm_trainer_create")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.dptm_trainer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward_backward(self, tok21, tok33, tok51, strct, esm, labels, n, opts: TrainOpts,
+                         want_loss: bool = True, stream=0):
+        loss = C.c_float(0.0)
+        rc = self._lib.dptm_trainer_forward_backward(
+            self._h, tok21, tok33, tok51, strct, esm, labels, n, C.byref(opts),
+            C.byref(loss) if want_loss else None, C.c_void_p(stream or None))
+        _check_t(self._lib, rc, "dptm_trainer_forward_backward")
+        return float(loss.value) if want_loss else None
+
+    def grad_buffer(self):
+        p = C.c_void_p()
+        n = C.c_int64()
+        _check_t(self._lib, self._lib.dptm_trainer_grad_buffer(self._h, C.byref(p), C.byref(n)),
+                 "dptm_trainer_grad_buffer")
+        return int(p.value), int(n.value)
+
+    def apply(self, lr: float, weight_decay: float, grad_scale: float = 1.0, stream=0) -> None:
+        rc = self._lib.dptm_trainer_apply(self._h, lr, weight_decay, grad_scale, C.c_void_p(stream or None))
+        _check_t(self._lib, rc, "dptm_trainer_apply")
+
+    def get_weights(self) -> np.ndarray:
+        out = np.empty(self.n_canonical, dtype=np.float32)
+        _check_t(self._lib, self._lib.dptm_trainer_get_weights(self._h, _ptr(out)), "dptm_trainer_get_weights")
+        return out
+
+    def get_grads(self) -> np.ndarray:
+        out = np.empty(self.n_canonical, dtype=np.float32)
+        _check_t(self._lib, self._lib.dptm_trainer_get_grads(self._h, _ptr(out)), "dptm_trainer_get_grads")
+        return out
+
+    def get_proba(self, n: int) -> np.ndarray:
+        out = np.empty((n, 2), dtype=np.float32)
+        _check_t(self._lib, self._lib.dptm_trainer_get_proba(self._h, _ptr(out), n), "dptm_trainer_get_proba")
+        return out

@@ -1,0 +1,542 @@
+// Training step behind the C ABI (dptm_trainer_* in include/dptm.h): parameter layout,
+// activation arena, the forward/backward launch sequence of the graph of
+// pred/train_PTM/model.py:143-210 in training mode, the loss of trainer.py:36-54 and the
+// AdamW update of trainer.py:305-306.  Host code only; kernels are in dptm_train_kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dptm.h"
+#include "dptm_layout.h"
+#include "dptm_train_kernels.h"
+
+using namespace dptm;
+
+namespace {
+
+thread_local std::string g_terr;
+int tfail(int code, const std::string& msg) {
+    g_terr = msg;
+    return code;
+}
+#define T_TRY(expr)                                                                         \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) return tfail(DPTM_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int kAlign = 64;  // every tensor starts on a 256-byte boundary of the flat buffers
+
+struct Tn {          // one tensor of the canonical order
+    int64_t off;     // offset in the aligned flat buffers (floats)
+    int64_t size;
+    int64_t canon;   // offset in the canonical blob
+    bool trainable;
+    bool l2;
+};
+
+struct BnP { int gamma, beta, mean, var; };
+struct TbP { int wq, bq, wk, bk, wv, bv, wo, bo, f1k, f1b, f2k, f2b, ln1g, ln1b, ln2g, ln2b; };
+struct BranchP { int emb, pos, sck, scb, c3ak, c3ab; BnP bn1; int c3bk, c3bb; BnP bn2; TbP tb[2]; int poolk, poolb; };
+struct DenseP { int k, b; BnP bn; };
+
+struct PMap {
+    std::vector<Tn> t;
+    int64_t total = 0, canon_total = 0;
+    BranchP br[3];
+    DenseP strct, esm1, esm2, t1, t2, head;
+    int add(int64_t size, bool trainable = true, bool l2 = false) {
+        Tn x{total, size, canon_total, trainable, l2};
+        t.push_back(x);
+        total += (size + kAlign - 1) / kAlign * kAlign;
+        canon_total += size;
+        return (int)t.size() - 1;
+    }
+    BnP add_bn(int n) { BnP b; b.gamma = add(n); b.beta = add(n); b.mean = add(n, false); b.var = add(n, false); return b; }
+    void build() {
+        const int W[3] = {21, 33, 51};
+        for (int b = 0; b < 3; ++b) {
+            BranchP& p = br[b];
+            p.emb = add(kCodes * kD); p.pos = add((int64_t)W[b] * kD);
+            p.sck = add(kD * kD, true, true); p.scb = add(kD);
+            p.c3ak = add(3 * kD * kD, true, true); p.c3ab = add(kD); p.bn1 = add_bn(kD);
+            p.c3bk = add(3 * kD * kD, true, true); p.c3bb = add(kD); p.bn2 = add_bn(kD);
+            for (int i = 0; i < 2; ++i) {
+                TbP& q = p.tb[i];
+                q.wq = add(kD * kD); q.bq = add(kD); q.wk = add(kD * kD); q.bk = add(kD);
+                q.wv = add(kD * kD); q.bv = add(kD); q.wo = add(kD * kD); q.bo = add(kD);
+                q.f1k = add(kD * kFF); q.f1b = add(kFF); q.f2k = add(kFF * kD); q.f2b = add(kD);
+                q.ln1g = add(kD); q.ln1b = add(kD); q.ln2g = add(kD); q.ln2b = add(kD);
+            }
+            p.poolk = add(kD); p.poolb = add(1);
+        }
+        strct.k = add(kStruct * kStructUnits); strct.b = add(kStructUnits); strct.bn = add_bn(kStructUnits);
+        esm1.k = add((int64_t)kEsm * kEsm1); esm1.b = add(kEsm1); esm1.bn = add_bn(kEsm1);
+        esm2.k = add(kEsm1 * kEsm2); esm2.b = add(kEsm2);
+        t1.k = add(kConcat * kT1, true, true); t1.b = add(kT1); t1.bn = add_bn(kT1);
+        t2.k = add(kT1 * kT2, true, true); t2.b = add(kT2); t2.bn = add_bn(kT2);
+        head.k = add(kT2 * 2); head.b = add(2);
+    }
+};
+
+// bump allocator over one device block
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, used = 0;
+    float* f(size_t n) {
+        size_t bytes = (n * sizeof(float) + 255) / 256 * 256;
+        if (used + bytes > cap) return nullptr;
+        float* p = reinterpret_cast<float*>(base + used);
+        used += bytes;
+        return p;
+    }
+};
+
+struct TbAct { float *x, *q, *k, *v, *prob, *o, *ao, *xh1, *inv1, *h, *f1, *u, *f2, *xh2, *inv2; };
+struct BranchAct {
+    int wlen;
+    float *x0, *s, *a1, *y1, *z1, *a2, *y2, *x1, *mi1, *mi2;   // mi = mean|inv of a BatchNorm
+    TbAct tb[2];
+    float *xout, *pa, *palpha;
+};
+
+}  // namespace
+
+struct dptm_trainer {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t max_batch = 0;
+    PMap pm;
+    float *W = nullptr, *G = nullptr, *M = nullptr, *V = nullptr, *S = nullptr;  // weights, grads, Adam moments, new BN stats
+    uint8_t* trainable = nullptr;
+    Arena arena;
+    BranchAct ba[3];
+    // per-site tensors
+    float *sa, *sy, *smi, *ea, *ey, *emi, *e1, *e2a, *concat, *t1a, *t1y, *t1mi, *t1z, *t2a, *t2y, *t2mi, *t2z, *proba;
+    float *d_loss = nullptr, *bnstat = nullptr, *bnsums = nullptr;
+    // gradient scratch
+    float *g64a, *g64b, *g64c, *g64d, *g256, *gq, *gk, *gv;   // [maxrows][64] / [maxrows][256]
+    float *dconcat, *d512a, *d512b, *d256a, *d256b, *d128;
+    int64_t step = 0;
+    int64_t last_n = 0;
+};
+
+namespace {
+
+const int kW[3] = {21, 33, 51};
+
+int alloc_acts(dptm_trainer* t) {
+    const int64_t B = t->max_batch;
+    Arena& A = t->arena;
+    auto need = [&](float*& p, size_t n) -> bool { p = A.f(n); return p != nullptr; };
+    bool ok = true;
+    for (int b = 0; b < 3; ++b) {
+        BranchAct& a = t->ba[b];
+        a.wlen = kW[b];
+        const size_t R = (size_t)B * kW[b], R64 = R * 64;
+        ok &= need(a.x0, R64) && need(a.s, R64) && need(a.a1, R64) && need(a.y1, R64) && need(a.z1, R64) &&
+              need(a.a2, R64) && need(a.y2, R64) && need(a.x1, R64) && need(a.mi1, 128) && need(a.mi2, 128);
+        for (int i = 0; i < 2; ++i) {
+            TbAct& q = a.tb[i];
+            ok &= need(q.q, R64) && need(q.k, R64) && need(q.v, R64) && need(q.prob, (size_t)B * 4 * kW[b] * kW[b]) &&
+                  need(q.o, R64) && need(q.ao, R64) && need(q.xh1, R64) && need(q.inv1, R) && need(q.h, R64) &&
+                  need(q.f1, R * 256) && need(q.u, R * 256) && need(q.f2, R64) && need(q.xh2, R64) && need(q.inv2, R);
+        }
+        ok &= need(a.tb[1].x, R64) && need(a.xout, R64) && need(a.pa, R) && need(a.palpha, R);
+        a.tb[0].x = a.x1;
+    }
+    ok &= need(t->sa, B * 128) && need(t->sy, B * 128) && need(t->smi, 256) && need(t->ea, B * 512) && need(t->ey, B * 512) &&
+          need(t->emi, 1024) && need(t->e1, B * 512) && need(t->e2a, B * 256) && need(t->concat, B * 576) &&
+          need(t->t1a, B * 512) && need(t->t1y, B * 512) && need(t->t1mi, 1024) && need(t->t1z, B * 512) &&
+          need(t->t2a, B * 256) && need(t->t2y, B * 256) && need(t->t2mi, 512) && need(t->t2z, B * 256) &&
+          need(t->proba, B * 2) && need(t->d_loss, 64) && need(t->bnstat, 1024) && need(t->bnsums, 1024);
+    const size_t RM = (size_t)B * 51;
+    ok &= need(t->g64a, RM * 64) && need(t->g64b, RM * 64) && need(t->g64c, RM * 64) && need(t->g64d, RM * 64) &&
+          need(t->g256, RM * 256) && need(t->gq, RM * 64) && need(t->gk, RM * 64) && need(t->gv, RM * 64) &&
+          need(t->dconcat, B * 576) && need(t->d512a, B * 512) && need(t->d512b, B * 512) && need(t->d256a, B * 256) &&
+          need(t->d256b, B * 256) && need(t->d128, B * 128);
+    return ok ? DPTM_OK : tfail(DPTM_ENOMEM, "dptm_trainer_create: activation arena too small");
+}
+
+size_t arena_bytes(int64_t B) {
+    size_t f = 0;
+    for (int b = 0; b < 3; ++b) {
+        const size_t R = (size_t)B * kW[b];
+        f += R * 64 * 9 + 2 * (R * 64 * 10 + R * 256 * 2 + R * 2 + (size_t)B * 4 * kW[b] * kW[b]) + R * 64 + R * 2;
+    }
+    f += (size_t)B * (128 * 2 + 512 * 3 + 256 + 576 + 512 * 3 + 256 * 3 + 2);
+    f += (size_t)B * 51 * (64 * 7 + 256) + (size_t)B * (576 + 1024 + 512 + 128);
+    return f * sizeof(float) + (size_t)512 * 256 + (1 << 20);   // + per-allocation rounding slack
+}
+
+struct Ctx {
+    dptm_trainer* t;
+    hipStream_t st;
+    float* W;
+    float* G;
+    float* w(int id) const { return W + t->pm.t[id].off; }
+    float* g(int id) const { return G + t->pm.t[id].off; }
+};
+
+// BatchNorm in training mode on y [rows][cols] -> z (may live inside a wider buffer)
+int bn_train_fwd(const Ctx& c, const float* y, float* z, int64_t ldz, int zoff, int64_t rows, int cols, const BnP& bn, float* mi) {
+    dptm_trainer* t = c.t;
+    T_TRY(hipMemsetAsync(t->bnstat, 0, 2 * cols * sizeof(float), c.st));
+    T_TRY(t_colsum2(y, nullptr, rows, cols, t->bnstat, c.st));
+    T_TRY(t_bn_finalize(t->bnstat, cols, rows, mi, c.w(bn.mean), c.w(bn.var), t->S + t->pm.t[bn.mean].off,
+                        t->S + t->pm.t[bn.var].off, c.st));
+    T_TRY(t_bn_fwd(y, z, rows, cols, mi, c.w(bn.gamma), c.w(bn.beta), ldz, zoff, c.st));
+    return DPTM_OK;
+}
+
+GemmArgs ga(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* out, int64_t ldo, int col_off,
+            int64_t m, int k, int cols, int shift = 0, int wlen = 0, int acc = 0) {
+    GemmArgs a;
+    a.x = x; a.ldx = ldx; a.w = w; a.ldw = ldw; a.bias = bias; a.out = out; a.ldo = ldo; a.col_off = col_off;
+    a.m = m; a.k = k; a.cols = cols; a.shift = shift; a.wlen = wlen; a.accumulate = acc;
+    return a;
+}
+GemmTnArgs gt(const float* x, int64_t ldx, int xoff, const float* dy, int64_t ldy, int dyoff, float* dw, int64_t ldw, float* db,
+              int64_t m, int k, int n, int shift = 0, int wlen = 0) {
+    GemmTnArgs a;
+    a.x = x; a.ldx = ldx; a.x_col_off = xoff; a.dy = dy; a.ldy = ldy; a.dy_col_off = dyoff; a.dw = dw; a.ldw = ldw; a.db = db;
+    a.m = m; a.k = k; a.n = n; a.shift = shift; a.wlen = wlen; a.rows_per_slab = 0;
+    return a;
+}
+
+// conv1d 'same' as taps: out = sum_t shift_{t-1}(x) * K[t] + b
+int conv_fwd(const Ctx& c, const float* x, int kid, int bid, int taps, float* out, int64_t R, int wlen) {
+    for (int tp = 0; tp < taps; ++tp) {
+        const int sh = taps == 1 ? 0 : tp - 1;
+        T_TRY(t_gemm(ga(x, 64, c.w(kid) + (size_t)tp * 64 * 64, 64, tp == 0 ? c.w(bid) : nullptr, out, 64, 0, R, 64, 64, sh, wlen,
+                        tp > 0), false, c.st));
+    }
+    return DPTM_OK;
+}
+// gradients of a conv: dK[t] += shift(x)^T dout, db += colsum(dout), dx (+)= sum_t shift_{-(t-1)}(dout) K[t]^T
+int conv_bwd(const Ctx& c, const float* x, const float* dout, int kid, int bid, int taps, float* dx, bool dx_acc, int64_t R, int wlen) {
+    for (int tp = 0; tp < taps; ++tp) {
+        const int sh = taps == 1 ? 0 : tp - 1;
+        T_TRY(t_gemm_tn(gt(x, 64, 0, dout, 64, 0, c.g(kid) + (size_t)tp * 64 * 64, 64, tp == 0 ? c.g(bid) : nullptr, R, 64, 64, sh,
+                           wlen), c.st));
+        if (dx)
+            T_TRY(t_gemm(ga(dout, 64, c.w(kid) + (size_t)tp * 64 * 64, 64, nullptr, dx, 64, 0, R, 64, 64, -sh, wlen,
+                            (dx_acc || tp > 0) ? 1 : 0), true, c.st));
+    }
+    return DPTM_OK;
+}
+
+struct Rates { float embed, conv, tb, dense; };
+
+int branch_fwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, unsigned seed, const Rates& rt) {
+    dptm_trainer* t = c.t;
+    BranchAct& a = t->ba[b];
+    const BranchP& p = t->pm.br[b];
+    const int wl = a.wlen;
+    const int64_t R = B * wl, R64 = R * 64;
+    int rc;
+    T_TRY(t_embed_fwd(tok, c.w(p.emb), c.w(p.pos), a.x0, R, wl, c.st));
+    T_TRY(t_dropout(a.x0, R, 64, 64, wl, seed, b * 8 + 0, rt.embed, c.st));
+    if ((rc = conv_fwd(c, a.x0, p.sck, p.scb, 1, a.s, R, wl))) return rc;
+    if ((rc = conv_fwd(c, a.x0, p.c3ak, p.c3ab, 3, a.a1, R, wl))) return rc;
+    T_TRY(t_swish_fwd(a.a1, a.y1, R64, c.st));
+    if ((rc = bn_train_fwd(c, a.y1, a.z1, 64, 0, R, 64, p.bn1, a.mi1))) return rc;
+    T_TRY(t_dropout(a.z1, R, 64, 64, wl, seed, b * 8 + 1, rt.conv, c.st));
+    if ((rc = conv_fwd(c, a.z1, p.c3bk, p.c3bb, 3, a.a2, R, wl))) return rc;
+    T_TRY(t_swish_fwd(a.a2, a.y2, R64, c.st));
+    if ((rc = bn_train_fwd(c, a.y2, a.x1, 64, 0, R, 64, p.bn2, a.mi2))) return rc;
+    T_TRY(t_add(a.x1, a.s, R64, c.st));
+    for (int i = 0; i < 2; ++i) {
+        TbAct& q = a.tb[i];
+        const TbP& w = p.tb[i];
+        float* xout = i == 0 ? a.tb[1].x : a.xout;
+        T_TRY(t_gemm(ga(q.x, 64, c.w(w.wq), 64, c.w(w.bq), q.q, 64, 0, R, 64, 64), false, c.st));
+        T_TRY(t_gemm(ga(q.x, 64, c.w(w.wk), 64, c.w(w.bk), q.k, 64, 0, R, 64, 64), false, c.st));
+        T_TRY(t_gemm(ga(q.x, 64, c.w(w.wv), 64, c.w(w.bv), q.v, 64, 0, R, 64, 64), false, c.st));
+        T_TRY(t_attn_fwd(q.q, q.k, q.v, q.o, q.prob, B, wl, c.st));
+        T_TRY(t_gemm(ga(q.o, 64, c.w(w.wo), 64, c.w(w.bo), q.ao, 64, 0, R, 64, 64), false, c.st));
+        T_TRY(t_dropout(q.ao, R, 64, 64, 0, seed, b * 8 + 2 + 2 * i, rt.tb, c.st));
+        T_TRY(t_ln_fwd(q.x, q.ao, c.w(w.ln1g), c.w(w.ln1b), q.h, q.xh1, q.inv1, R, c.st));
+        T_TRY(t_gemm(ga(q.h, 64, c.w(w.f1k), 256, c.w(w.f1b), q.f1, 256, 0, R, 64, 256), false, c.st));
+        T_TRY(t_swish_fwd(q.f1, q.u, R * 256, c.st));
+        T_TRY(t_gemm(ga(q.u, 256, c.w(w.f2k), 64, c.w(w.f2b), q.f2, 64, 0, R, 256, 64), false, c.st));
+        T_TRY(t_dropout(q.f2, R, 64, 64, 0, seed, b * 8 + 3 + 2 * i, rt.tb, c.st));
+        T_TRY(t_ln_fwd(q.h, q.f2, c.w(w.ln2g), c.w(w.ln2b), xout, q.xh2, q.inv2, R, c.st));
+    }
+    T_TRY(t_pool_fwd(a.xout, c.w(p.poolk), c.w(p.poolb), t->concat, kConcat, b * 64, a.pa, a.palpha, B, wl, c.st));
+    return DPTM_OK;
+}
+
+// dpool = d(concat)[:, b*64 .. +64]  ->  all parameter gradients of branch b
+int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, unsigned seed, const Rates& rt) {
+    dptm_trainer* t = c.t;
+    BranchAct& a = t->ba[b];
+    const BranchP& p = t->pm.br[b];
+    const int wl = a.wlen;
+    const int64_t R = B * wl, R64 = R * 64;
+    int rc;
+    float* dx = t->g64a;      // gradient w.r.t. the block output / running d(x)
+    float* dsum = t->g64b;
+    float* tmp = t->g64c;
+    float* dh = t->g64d;
+    T_TRY(t_pool_bwd(a.xout, c.w(p.poolk), t->dconcat, kConcat, b * 64, a.pa, a.palpha, dx, c.g(p.poolk), c.g(p.poolb), B, wl, c.st));
+    for (int i = 1; i >= 0; --i) {
+        TbAct& q = a.tb[i];
+        const TbP& w = p.tb[i];
+        // LayerNorm 2: dsum = d(h + f2)
+        T_TRY(t_ln_bwd(dx, q.xh2, q.inv2, c.w(w.ln2g), dsum, c.g(w.ln2g), c.g(w.ln2b), R, c.st));
+        // f2 branch: dropout, ffn2, swish, ffn1
+        T_TRY(hipMemcpyAsync(tmp, dsum, R64 * sizeof(float), hipMemcpyDeviceToDevice, c.st));
+        T_TRY(t_dropout(tmp, R, 64, 64, 0, seed, b * 8 + 3 + 2 * i, rt.tb, c.st));
+        T_TRY(t_gemm_tn(gt(q.u, 256, 0, tmp, 64, 0, c.g(w.f2k), 64, c.g(w.f2b), R, 256, 64), c.st));
+        T_TRY(t_gemm(ga(tmp, 64, c.w(w.f2k), 64, nullptr, t->g256, 256, 0, R, 64, 256), true, c.st));       // dU
+        T_TRY(t_swish_bwd(q.f1, t->g256, t->g256, R * 256, c.st));                                           // dF1
+        T_TRY(t_gemm_tn(gt(q.h, 64, 0, t->g256, 256, 0, c.g(w.f1k), 256, c.g(w.f1b), R, 64, 256), c.st));
+        T_TRY(hipMemcpyAsync(dh, dsum, R64 * sizeof(float), hipMemcpyDeviceToDevice, c.st));                 // dH = dsum + ...
+        T_TRY(t_gemm(ga(t->g256, 256, c.w(w.f1k), 256, nullptr, dh, 64, 0, R, 256, 64, 0, 0, 1), true, c.st));
+        // LayerNorm 1: dsum = d(x + ao)
+        T_TRY(t_ln_bwd(dh, q.xh1, q.inv1, c.w(w.ln1g), dsum, c.g(w.ln1g), c.g(w.ln1b), R, c.st));
+        T_TRY(hipMemcpyAsync(tmp, dsum, R64 * sizeof(float), hipMemcpyDeviceToDevice, c.st));
+        T_TRY(t_dropout(tmp, R, 64, 64, 0, seed, b * 8 + 2 + 2 * i, rt.tb, c.st));                           // dAO
+        T_TRY(t_gemm_tn(gt(q.o, 64, 0, tmp, 64, 0, c.g(w.wo), 64, c.g(w.bo), R, 64, 64), c.st));
+        T_TRY(t_gemm(ga(tmp, 64, c.w(w.wo), 64, nullptr, dh, 64, 0, R, 64, 64), true, c.st));                // dO (in dh)
+        T_TRY(t_attn_bwd(q.q, q.k, q.v, q.prob, dh, t->gq, t->gk, t->gv, B, wl, c.st));
+        T_TRY(t_gemm_tn(gt(q.x, 64, 0, t->gq, 64, 0, c.g(w.wq), 64, c.g(w.bq), R, 64, 64), c.st));
+        T_TRY(t_gemm_tn(gt(q.x, 64, 0, t->gk, 64, 0, c.g(w.wk), 64, c.g(w.bk), R, 64, 64), c.st));
+        T_TRY(t_gemm_tn(gt(q.x, 64, 0, t->gv, 64, 0, c.g(w.wv), 64, c.g(w.bv), R, 64, 64), c.st));
+        // dX = dsum + dQ Wq^T + dK Wk^T + dV Wv^T   (written into dx)
+        T_TRY(hipMemcpyAsync(dx, dsum, R64 * sizeof(float), hipMemcpyDeviceToDevice, c.st));
+        T_TRY(t_gemm(ga(t->gq, 64, c.w(w.wq), 64, nullptr, dx, 64, 0, R, 64, 64, 0, 0, 1), true, c.st));
+        T_TRY(t_gemm(ga(t->gk, 64, c.w(w.wk), 64, nullptr, dx, 64, 0, R, 64, 64, 0, 0, 1), true, c.st));
+        T_TRY(t_gemm(ga(t->gv, 64, c.w(w.wv), 64, nullptr, dx, 64, 0, R, 64, 64, 0, 0, 1), true, c.st));
+    }
+    // conv block: x1 = BN2(swish(conv3b(z1))) + conv1(x0); dx = d(x1)
+    // BatchNorm 2 -> dY2 (tmp) -> dA2 (tmp)
+    T_TRY(t_bn_bwd(dx, 64, 0, a.y2, tmp, R, 64, a.mi2, c.w(p.bn2.gamma), t->bnsums, c.g(p.bn2.gamma), c.g(p.bn2.beta), c.st));
+    T_TRY(t_swish_bwd(a.a2, tmp, tmp, R64, c.st));
+    if ((rc = conv_bwd(c, a.z1, tmp, p.c3bk, p.c3bb, 3, dsum, false, R, wl))) return rc;     // dsum = dZ1 (after dropout)
+    T_TRY(t_dropout(dsum, R, 64, 64, wl, seed, b * 8 + 1, rt.conv, c.st));
+    T_TRY(t_bn_bwd(dsum, 64, 0, a.y1, tmp, R, 64, a.mi1, c.w(p.bn1.gamma), t->bnsums, c.g(p.bn1.gamma), c.g(p.bn1.beta), c.st));
+    T_TRY(t_swish_bwd(a.a1, tmp, tmp, R64, c.st));                                          // dA1
+    if ((rc = conv_bwd(c, a.x0, tmp, p.c3ak, p.c3ab, 3, dh, false, R, wl))) return rc;       // dh = dX0 from conv3a
+    if ((rc = conv_bwd(c, a.x0, dx, p.sck, p.scb, 1, dh, true, R, wl))) return rc;           // += shortcut path
+    T_TRY(t_dropout(dh, R, 64, 64, wl, seed, b * 8 + 0, rt.embed, c.st));
+    T_TRY(t_embed_bwd(tok, dh, c.g(p.emb), c.g(p.pos), R, wl, c.st));
+    return DPTM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dptm_trainer_last_error(void) { return g_terr.c_str(); }
+
+void dptm_trainer_destroy(dptm_trainer* t) {
+    if (!t) return;
+    (void)hipSetDevice(t->device);
+    if (t->stream) (void)hipStreamSynchronize(t->stream);
+    void* bufs[] = {t->W, t->G, t->M, t->V, t->S, t->trainable, t->arena.base};
+    for (void* p : bufs)
+        if (p) (void)hipFree(p);
+    if (t->stream) (void)hipStreamDestroy(t->stream);
+    delete t;
+}
+
+int64_t dptm_trainer_param_floats(const dptm_trainer* t) { return t ? t->pm.total : 0; }
+
+int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spec, int device, int64_t max_batch,
+                        dptm_trainer** out) {
+    if (!out) return tfail(DPTM_EINVAL, "dptm_trainer_create: out is NULL");
+    *out = nullptr;
+    if (!weights || max_batch < 1) return tfail(DPTM_EINVAL, "dptm_trainer_create: bad argument");
+    if (dptm_weight_count(spec) < 0) return tfail(DPTM_EINVAL, "dptm_trainer_create: unsupported model spec");
+    dptm_trainer* t = new (std::nothrow) dptm_trainer();
+    if (!t) return tfail(DPTM_ENOMEM, "dptm_trainer_create: out of host memory");
+    t->pm.build();
+    if ((int64_t)(nbytes / sizeof(float)) != t->pm.canon_total) {
+        delete t;
+        return tfail(DPTM_EINVAL, "dptm_trainer_create: weight blob has the wrong size");
+    }
+    t->device = device;
+    t->max_batch = max_batch;
+    auto bail = [&](int code, const char* msg) {
+        dptm_trainer_destroy(t);
+        return tfail(code, msg);
+    };
+    if (hipSetDevice(device) != hipSuccess) return bail(DPTM_EINVAL, "dptm_trainer_create: no such device");
+    if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) return bail(DPTM_EHIP, "hipStreamCreate failed");
+    const size_t pb = (size_t)t->pm.total * sizeof(float);
+    if (hipMalloc((void**)&t->W, pb) != hipSuccess || hipMalloc((void**)&t->G, pb) != hipSuccess ||
+        hipMalloc((void**)&t->M, pb) != hipSuccess || hipMalloc((void**)&t->V, pb) != hipSuccess ||
+        hipMalloc((void**)&t->S, pb) != hipSuccess || hipMalloc((void**)&t->trainable, (size_t)t->pm.total) != hipSuccess)
+        return bail(DPTM_ENOMEM, "dptm_trainer_create: parameter buffers");
+    std::vector<float> host((size_t)t->pm.total, 0.0f);
+    std::vector<uint8_t> tr((size_t)t->pm.total, 0);
+    const float* src = static_cast<const float*>(weights);
+    for (const Tn& x : t->pm.t) {
+        std::memcpy(host.data() + x.off, src + x.canon, (size_t)x.size * sizeof(float));
+        if (x.trainable) std::memset(tr.data() + x.off, 1, (size_t)x.size);
+    }
+    if (hipMemcpy(t->W, host.data(), pb, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(t->S, host.data(), pb, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(t->trainable, tr.data(), tr.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(t->G, 0, pb) != hipSuccess || hipMemset(t->M, 0, pb) != hipSuccess || hipMemset(t->V, 0, pb) != hipSuccess)
+        return bail(DPTM_EHIP, "dptm_trainer_create: parameter upload");
+    t->arena.cap = arena_bytes(max_batch);
+    if (hipMalloc((void**)&t->arena.base, t->arena.cap) != hipSuccess) return bail(DPTM_ENOMEM, "dptm_trainer_create: activation arena");
+    int rc = alloc_acts(t);
+    if (rc) {
+        std::string keep = g_terr;
+        dptm_trainer_destroy(t);
+        g_terr = keep;
+        return rc;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return bail(DPTM_EHIP, "dptm_trainer_create: sync");
+    *out = t;
+    return DPTM_OK;
+}
+
+int dptm_trainer_grad_buffer(dptm_trainer* t, float** dev_ptr, int64_t* count) {
+    if (!t || !dev_ptr || !count) return tfail(DPTM_EINVAL, "dptm_trainer_grad_buffer: NULL argument");
+    *dev_ptr = t->G;
+    *count = t->pm.total;
+    return DPTM_OK;
+}
+
+// Forward in training mode + loss + backward for one local batch (device pointers).
+int dptm_trainer_forward_backward(dptm_trainer* t, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
+                                  const float* strct, const float* esm, const int32_t* labels, int64_t n,
+                                  const dptm_train_opts* o, float* loss_out, void* stream) {
+    if (!t || !o) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward: NULL argument");
+    if (n < 1 || n > t->max_batch) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward: batch size outside 1..max_batch");
+    if (!tok21 || !tok33 || !tok51 || !strct || !esm || !labels) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward: NULL buffer");
+    T_TRY(hipSetDevice(t->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : t->stream;
+    Ctx c{t, st, t->W, t->G};
+    const PMap& pm = t->pm;
+    const Rates rt{o->rate_embed, o->rate_conv, o->rate_tb, o->rate_dense};
+    const unsigned seed = o->seed;
+    const uint8_t* tok[3] = {tok21, tok33, tok51};
+    const int64_t B = n;
+    int rc;
+    T_TRY(hipMemsetAsync(t->G, 0, (size_t)pm.total * sizeof(float), st));
+    T_TRY(hipMemsetAsync(t->d_loss, 0, 64 * sizeof(float), st));
+    // ---------------- forward
+    for (int b = 0; b < 3; ++b)
+        if ((rc = branch_fwd(c, b, tok[b], B, seed, rt))) return rc;
+    // struct branch (model.py:187-189)
+    T_TRY(t_gemm(ga(strct, 8, c.w(pm.strct.k), 128, c.w(pm.strct.b), t->sa, 128, 0, B, 8, 128), false, st));
+    T_TRY(t_swish_fwd(t->sa, t->sy, B * 128, st));
+    if ((rc = bn_train_fwd(c, t->sy, t->concat, kConcat, 192, B, 128, pm.strct.bn, t->smi))) return rc;
+    T_TRY(t_dropout(t->concat + 192, B, 128, kConcat, 0, seed, 24 + 0, rt.dense, st));
+    // ESM branch (model.py:191-194)
+    T_TRY(t_gemm(ga(esm, kEsm, c.w(pm.esm1.k), 512, c.w(pm.esm1.b), t->ea, 512, 0, B, kEsm, 512), false, st));
+    T_TRY(t_swish_fwd(t->ea, t->ey, B * 512, st));
+    if ((rc = bn_train_fwd(c, t->ey, t->e1, 512, 0, B, 512, pm.esm1.bn, t->emi))) return rc;
+    T_TRY(t_dropout(t->e1, B, 512, 512, 0, seed, 24 + 1, rt.dense, st));
+    T_TRY(t_gemm(ga(t->e1, 512, c.w(pm.esm2.k), 256, c.w(pm.esm2.b), t->e2a, 256, 0, B, 512, 256), false, st));
+    {   // swish into the concat columns 320..575
+        T_TRY(t_swish_fwd(t->e2a, t->d256a, B * 256, st));
+        T_TRY(t_copy_cols(t->concat, kConcat, 320, t->d256a, 256, 0, B, 256, false, st));
+    }
+    T_TRY(t_dropout(t->concat, B, kConcat, kConcat, 0, seed, 24 + 2, rt.dense, st));
+    // trunk (model.py:200-205)
+    T_TRY(t_gemm(ga(t->concat, kConcat, c.w(pm.t1.k), 512, c.w(pm.t1.b), t->t1a, 512, 0, B, kConcat, 512), false, st));
+    T_TRY(t_swish_fwd(t->t1a, t->t1y, B * 512, st));
+    if ((rc = bn_train_fwd(c, t->t1y, t->t1z, 512, 0, B, 512, pm.t1.bn, t->t1mi))) return rc;
+    T_TRY(t_dropout(t->t1z, B, 512, 512, 0, seed, 24 + 3, rt.dense, st));
+    T_TRY(t_gemm(ga(t->t1z, 512, c.w(pm.t2.k), 256, c.w(pm.t2.b), t->t2a, 256, 0, B, 512, 256), false, st));
+    T_TRY(t_swish_fwd(t->t2a, t->t2y, B * 256, st));
+    if ((rc = bn_train_fwd(c, t->t2y, t->t2z, 256, 0, B, 256, pm.t2.bn, t->t2mi))) return rc;
+    // ---------------- head, loss and its gradient (trainer.py:36-54)
+    const float ng = o->n_global > 0 ? (float)o->n_global : (float)B;
+    float npos = (float)o->n_pos_global;
+    T_TRY(t_head_loss(t->t2z, c.w(pm.head.k), c.w(pm.head.b), labels, B, ng, npos, t->proba, t->d_loss, t->d256a,
+                      c.g(pm.head.k), c.g(pm.head.b), st));
+    // ---------------- backward, per-site layers
+    // trunk 2: BN -> swish -> dense
+    T_TRY(t_bn_bwd(t->d256a, 256, 0, t->t2y, t->d256b, B, 256, t->t2mi, c.w(pm.t2.bn.gamma), t->bnsums, c.g(pm.t2.bn.gamma), c.g(pm.t2.bn.beta), st));
+    T_TRY(t_swish_bwd(t->t2a, t->d256b, t->d256b, B * 256, st));
+    T_TRY(t_gemm_tn(gt(t->t1z, 512, 0, t->d256b, 256, 0, c.g(pm.t2.k), 256, c.g(pm.t2.b), B, 512, 256), st));
+    T_TRY(t_gemm(ga(t->d256b, 256, c.w(pm.t2.k), 256, nullptr, t->d512a, 512, 0, B, 256, 512), true, st));
+    T_TRY(t_dropout(t->d512a, B, 512, 512, 0, seed, 24 + 3, rt.dense, st));
+    T_TRY(t_bn_bwd(t->d512a, 512, 0, t->t1y, t->d512b, B, 512, t->t1mi, c.w(pm.t1.bn.gamma), t->bnsums, c.g(pm.t1.bn.gamma), c.g(pm.t1.bn.beta), st));
+    T_TRY(t_swish_bwd(t->t1a, t->d512b, t->d512b, B * 512, st));
+    T_TRY(t_gemm_tn(gt(t->concat, kConcat, 0, t->d512b, 512, 0, c.g(pm.t1.k), 512, c.g(pm.t1.b), B, kConcat, 512), st));
+    T_TRY(t_gemm(ga(t->d512b, 512, c.w(pm.t1.k), 512, nullptr, t->dconcat, kConcat, 0, B, 512, kConcat), true, st));
+    T_TRY(t_dropout(t->dconcat, B, kConcat, kConcat, 0, seed, 24 + 2, rt.dense, st));
+    // ESM branch: d(concat[:,320:]) -> swish -> dense2 -> dropout -> BN -> swish -> dense1
+    T_TRY(t_copy_cols(t->d256a, 256, 0, t->dconcat, kConcat, 320, B, 256, false, st));
+    T_TRY(t_swish_bwd(t->e2a, t->d256a, t->d256a, B * 256, st));
+    T_TRY(t_gemm_tn(gt(t->e1, 512, 0, t->d256a, 256, 0, c.g(pm.esm2.k), 256, c.g(pm.esm2.b), B, 512, 256), st));
+    T_TRY(t_gemm(ga(t->d256a, 256, c.w(pm.esm2.k), 256, nullptr, t->d512a, 512, 0, B, 256, 512), true, st));
+    T_TRY(t_dropout(t->d512a, B, 512, 512, 0, seed, 24 + 1, rt.dense, st));
+    T_TRY(t_bn_bwd(t->d512a, 512, 0, t->ey, t->d512b, B, 512, t->emi, c.w(pm.esm1.bn.gamma), t->bnsums, c.g(pm.esm1.bn.gamma), c.g(pm.esm1.bn.beta), st));
+    T_TRY(t_swish_bwd(t->ea, t->d512b, t->d512b, B * 512, st));
+    T_TRY(t_gemm_tn(gt(esm, kEsm, 0, t->d512b, 512, 0, c.g(pm.esm1.k), 512, c.g(pm.esm1.b), B, kEsm, 512), st));
+    // struct branch: d(concat[:,192:320]) -> dropout -> BN -> swish -> dense
+    T_TRY(t_copy_cols(t->d128, 128, 0, t->dconcat, kConcat, 192, B, 128, false, st));
+    T_TRY(t_dropout(t->d128, B, 128, 128, 0, seed, 24 + 0, rt.dense, st));
+    T_TRY(t_bn_bwd(t->d128, 128, 0, t->sy, t->d512a, B, 128, t->smi, c.w(pm.strct.bn.gamma), t->bnsums, c.g(pm.strct.bn.gamma), c.g(pm.strct.bn.beta), st));
+    T_TRY(t_swish_bwd(t->sa, t->d512a, t->d512a, B * 128, st));
+    T_TRY(t_gemm_tn(gt(strct, 8, 0, t->d512a, 128, 0, c.g(pm.strct.k), 128, c.g(pm.strct.b), B, 8, 128), st));
+    // sequence branches
+    for (int b = 0; b < 3; ++b)
+        if ((rc = branch_bwd(c, b, tok[b], B, seed, rt))) return rc;
+    // l2 kernel regularisers (model.py:130-138,200,204): value into the loss, 2*lambda*w into the gradient
+    if (o->l2 > 0.f)
+        for (const Tn& x : pm.t)
+            if (x.l2) T_TRY(t_l2(t->W + x.off, t->G + x.off, x.size, o->l2 * o->l2_scale, t->d_loss, st));
+    t->last_n = n;
+    if (loss_out) {
+        T_TRY(hipMemcpyAsync(loss_out, t->d_loss, sizeof(float), hipMemcpyDeviceToHost, st));
+        T_TRY(hipStreamSynchronize(st));
+    }
+    return DPTM_OK;
+}
+
+// tensorflow-addons AdamW step on the flat buffers (gradients are multiplied by grad_scale first).
+int dptm_trainer_apply(dptm_trainer* t, float lr, float weight_decay, float grad_scale, void* stream) {
+    if (!t) return tfail(DPTM_EINVAL, "dptm_trainer_apply: NULL trainer");
+    T_TRY(hipSetDevice(t->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : t->stream;
+    t->step += 1;
+    const double b1 = 0.9, b2 = 0.999;
+    const float lr_t = (float)(lr * std::sqrt(1.0 - std::pow(b2, (double)t->step)) / (1.0 - std::pow(b1, (double)t->step)));
+    T_TRY(t_adamw(t->W, t->G, t->M, t->V, t->trainable, t->S, t->pm.total, lr_t, weight_decay, (float)b1, (float)b2, 1e-7f,
+                  grad_scale, st));
+    return DPTM_OK;
+}
+
+static int copy_out(dptm_trainer* t, const float* dev, float* host_canonical) {
+    std::vector<float> host((size_t)t->pm.total);
+    T_TRY(hipSetDevice(t->device));
+    T_TRY(hipStreamSynchronize(t->stream));
+    T_TRY(hipDeviceSynchronize());
+    T_TRY(hipMemcpy(host.data(), dev, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (const Tn& x : t->pm.t) std::memcpy(host_canonical + x.canon, host.data() + x.off, (size_t)x.size * sizeof(float));
+    return DPTM_OK;
+}
+
+// Weights / gradients in the canonical blob order (host buffers of dptm_weight_count floats).
+int dptm_trainer_get_weights(dptm_trainer* t, float* host_out) {
+    if (!t || !host_out) return tfail(DPTM_EINVAL, "dptm_trainer_get_weights: NULL argument");
+    return copy_out(t, t->W, host_out);
+}
+int dptm_trainer_get_grads(dptm_trainer* t, float* host_out) {
+    if (!t || !host_out) return tfail(DPTM_EINVAL, "dptm_trainer_get_grads: NULL argument");
+    return copy_out(t, t->G, host_out);
+}
+int dptm_trainer_get_proba(dptm_trainer* t, float* host_out, int64_t n) {
+    if (!t || !host_out || n < 0 || n > t->max_batch) return tfail(DPTM_EINVAL, "dptm_trainer_get_proba: bad argument");
+    T_TRY(hipSetDevice(t->device));
+    T_TRY(hipDeviceSynchronize());
+    T_TRY(hipMemcpy(host_out, t->proba, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    return DPTM_OK;
+}
+
+}  // extern "C"

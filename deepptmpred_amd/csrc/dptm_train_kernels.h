@@ -1,0 +1,79 @@
+// Launcher interface of the training kernels (dptm_train_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace dptm {
+
+struct GemmArgs {
+    const float* x;      // [m][ldx]
+    int64_t ldx;
+    const float* w;      // NN: [k][ldw] ; NT: [cols][ldw]
+    int64_t ldw;
+    const float* bias;   // [cols] or nullptr
+    float* out;          // [m][ldo], written at column col_off
+    int64_t ldo;
+    int col_off;
+    int64_t m;
+    int k;               // contraction length (multiple of 8)
+    int cols;            // output columns (multiple of 64)
+    int shift;           // input row = output row + shift, inside the same window
+    int wlen;            // window length of the row stack (0: rows are independent)
+    int accumulate;      // out += result
+};
+
+struct GemmTnArgs {
+    const float* x;      // [m][ldx], columns x_col_off .. x_col_off+k
+    int64_t ldx;
+    int x_col_off;
+    const float* dy;     // [m][ldy], columns dy_col_off .. dy_col_off+n
+    int64_t ldy;
+    int dy_col_off;
+    float* dw;           // [k][ldw] accumulated with atomics
+    int64_t ldw;
+    float* db;           // [n] or nullptr
+    int64_t m;
+    int k;
+    int n;               // multiple of 32
+    int shift;
+    int wlen;
+    int64_t rows_per_slab;   // set by the launcher
+};
+
+hipError_t t_gemm(const GemmArgs& a, bool nt, hipStream_t st);
+hipError_t t_gemm_tn(GemmTnArgs a, hipStream_t st);
+hipError_t t_swish_fwd(const float* a, float* y, int64_t n, hipStream_t st);
+hipError_t t_swish_bwd(const float* a, const float* dy, float* da, int64_t n, hipStream_t st);
+hipError_t t_add(float* dst, const float* src, int64_t n, hipStream_t st);
+hipError_t t_copy_cols(float* dst, int64_t ldd, int dc, const float* src, int64_t lds_, int sc, int64_t rows,
+                       int cols, bool add, hipStream_t st);
+hipError_t t_dropout(float* x, int64_t rows, int cols, int64_t ld, int wlen_spatial, unsigned seed, unsigned stream,
+                     float rate, hipStream_t st);
+hipError_t t_embed_fwd(const uint8_t* tok, const float* E, const float* P, float* x, int64_t rows, int wlen, hipStream_t st);
+hipError_t t_embed_bwd(const uint8_t* tok, const float* dx, float* dE, float* dP, int64_t rows, int wlen, hipStream_t st);
+hipError_t t_colsum2(const float* x, const float* y, int64_t rows, int cols, float* stats, hipStream_t st);
+hipError_t t_bn_finalize(const float* stats, int cols, int64_t rows, float* mean_inv, const float* mov_mean,
+                         const float* mov_var, float* new_mean, float* new_var, hipStream_t st);
+hipError_t t_bn_fwd(const float* y, float* z, int64_t rows, int cols, const float* mean_inv, const float* gamma,
+                    const float* beta, int64_t ldz, int z_col_off, hipStream_t st);
+hipError_t t_bn_bwd(const float* dz, int64_t lddz, int dz_col_off, const float* y, float* dy, int64_t rows, int cols,
+                    const float* mean_inv, const float* gamma, float* sums, float* dgamma, float* dbeta, hipStream_t st);
+hipError_t t_ln_fwd(const float* a, const float* b, const float* g, const float* beta, float* out, float* xhat,
+                    float* inv, int64_t rows, hipStream_t st);
+hipError_t t_ln_bwd(const float* dy, const float* xhat, const float* inv, const float* g, float* dsum, float* dg,
+                    float* dbeta, int64_t rows, hipStream_t st);
+hipError_t t_attn_fwd(const float* q, const float* k, const float* v, float* o, float* prob, int64_t samples, int wlen, hipStream_t st);
+hipError_t t_attn_bwd(const float* q, const float* k, const float* v, const float* prob, const float* d_o, float* dq,
+                      float* dk, float* dv, int64_t samples, int wlen, hipStream_t st);
+hipError_t t_pool_fwd(const float* x, const float* w, const float* bias, float* out, int64_t ldo, int col_off, float* a_save,
+                      float* alpha_save, int64_t samples, int wlen, hipStream_t st);
+hipError_t t_pool_bwd(const float* x, const float* w, const float* dout, int64_t ldd, int col_off, const float* a_save,
+                      const float* alpha_save, float* dx, float* dw, float* db, int64_t samples, int wlen, hipStream_t st);
+hipError_t t_head_loss(const float* x, const float* W, const float* bias, const int32_t* labels, int64_t n, float n_global,
+                       float n_pos_global, float* proba, float* loss, float* dx, float* dW, float* db, hipStream_t st);
+hipError_t t_l2(const float* w, float* g, int64_t n, float lambda, float* loss, hipStream_t st);
+hipError_t t_adamw(float* w, const float* g, float* m, float* v, const uint8_t* trainable, const float* stat, int64_t n,
+                   float lr_t, float wd, float b1, float b2, float eps, float gscale, hipStream_t st);
+
+}  // namespace dptm

@@ -1,0 +1,804 @@
+// HIP kernels (gfx950) for one training step of DeepPTMPred's classifier: forward in
+// training mode, backward and the AdamW update (reference: pred/train_PTM/trainer.py:
+// 36-54, 304-339 on the graph of pred/train_PTM/model.py:143-210).
+//
+// Layer-wise design: activations live in HBM as row-major fp32 [rows][features]
+// (rows = sample*W + position for the sequence branches, rows = samples for the
+// per-site layers), weights and gradients in ONE flat fp32 buffer each, in the canonical
+// tensor order (Keras shapes, unpacked).  Matrix products run on
+// v_mfma_f32_32x32x2_f32 straight from global memory:
+//   tgemm<NN>  Y  = shift(X) * W (+b)      forward dense / conv tap
+//   tgemm<NT>  dX = shift(dY) * W^T        input gradients
+//   tgemm_tn   dW += shift(X)^T * dY       weight gradients (+ bias gradient)
+#include <hip/hip_runtime.h>
+
+#include "dptm_train_kernels.h"
+
+namespace dptm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void mfma2(f32x16& acc, float a, float b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// stateless dropout stream: lowbias32 of the element index mixed with (seed, stream)
+__device__ __forceinline__ unsigned hash_u32(unsigned seed, unsigned stream, unsigned idx) {
+    unsigned x = idx ^ (seed * 0x9E3779B9u);
+    x += stream * 0x85EBCA6Bu;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
+// row r of a [samples*wlen] stack shifted by s stays inside its own window?
+__device__ __forceinline__ bool row_ok(int64_t r, int s, int64_t m, int wlen) {
+    if (r >= m) return false;
+    if (s == 0 || wlen == 0) return true;
+    const int p = (int)(r % wlen) + s;
+    return p >= 0 && p < wlen;
+}
+
+// ------------------------------------------------------------------------------------
+// out[r][c0..c0+63] (+)= sum_j in[r+s][j] * Wm(j, c) (+ bias[c])
+//   NN: Wm(j,c) = W[j*ldw + c]   (W is [K][N], contraction over its rows)
+//   NT: Wm(j,c) = W[c*ldw + j]   (W is [C][J], contraction over its columns)
+// One wavefront: 32 rows x 64 columns.  grid = (ceil(m/128), cols/64), block 256.
+// ------------------------------------------------------------------------------------
+template <bool NT>
+__global__ __launch_bounds__(256) void tgemm_kernel(GemmArgs p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    if (r0 >= p.m) return;
+    const int c0 = blockIdx.y * 64;
+    const int64_t r = r0 + j;
+    const bool ok = row_ok(r, p.shift, p.m, p.wlen);
+    const float* xin = p.x + (ok ? (r + p.shift) : 0) * p.ldx + 4 * h;
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc[t][4 * g + e] = p.bias ? p.bias[c0 + 32 * t + 8 * g + 4 * h + e] : 0.f;
+    const int k8 = p.k >> 3;
+    for (int u = 0; u < k8; ++u) {
+        f32x4 b = *reinterpret_cast<const f32x4*>(xin + 8 * u);
+        if (!ok) b = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 a[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int c = c0 + 32 * t + j;
+            if (NT) {
+                a[t] = *reinterpret_cast<const f32x4*>(p.w + (int64_t)c * p.ldw + 8 * u + 4 * h);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[t][e] = p.w[(int64_t)(8 * u + 4 * h + e) * p.ldw + c];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) mfma2(acc[t], a[t][e], b[e]);
+    }
+    if (r >= p.m) return;
+    float* orow = p.out + r * p.ldo + p.col_off + c0 + 4 * h;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+            f32x4* dst = reinterpret_cast<f32x4*>(orow + 32 * t + 8 * g);
+            if (p.accumulate) v += *dst;
+            *dst = v;
+        }
+}
+
+// ------------------------------------------------------------------------------------
+// dW[k][n] += sum_r X[r+s][k] * dY[r][n];  db[n] += sum_r dY[r][n] (blocks with k-tile 0).
+// One wavefront: a 32(k) x 32(n) tile over a slab of rows; results added with float atomics.
+// grid = (ceil(K/32), N/32, row slabs), block 64.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void tgemm_tn_kernel(GemmTnArgs p) {
+    const int lane = threadIdx.x, h = lane >> 5, i = lane & 31;
+    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int64_t rs = (int64_t)blockIdx.z * p.rows_per_slab;
+    const int64_t re = min(p.m, rs + p.rows_per_slab);
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const bool kin = k0 + i < p.k;
+    for (int64_t rr = rs; rr < re; rr += 2) {   // half-wave h takes row rr+h of every pair
+        const int64_t r = rr + h;
+        float a = 0.f, b = 0.f;
+        if (r < re) {
+            b = p.dy[r * p.ldy + p.dy_col_off + n0 + i];
+            if (kin && row_ok(r, p.shift, p.m, p.wlen)) a = p.x[(r + p.shift) * p.ldx + p.x_col_off + k0 + i];
+        }
+        mfma2(acc, a, b);
+        bsum += b;
+    }
+    // D[row = k][col = n]: lane holds column n0+i, rows (reg&3) + 8*(reg>>2) + 4*h
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+        const int k = k0 + (rg & 3) + 8 * (rg >> 2) + 4 * h;
+        if (k < p.k) atomicAdd(p.dw + (int64_t)k * p.ldw + n0 + i, acc[rg]);
+    }
+    if (p.db && blockIdx.x == 0) {
+        bsum += __shfl_xor(bsum, 32);
+        if (h == 0) atomicAdd(p.db + n0 + i, bsum);
+    }
+}
+
+// ------------------------------------------------------------------------------------ elementwise
+
+__global__ void swish_fwd_kernel(const float* __restrict__ a, float* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = a[i];
+        y[i] = v * sigmoidf_(v);
+    }
+}
+
+// da = dy * d/da[a*sigmoid(a)]   (in place on dy allowed)
+__global__ void swish_bwd_kernel(const float* __restrict__ a, const float* __restrict__ dy,
+                                 float* __restrict__ da, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = a[i], s = sigmoidf_(v);
+        da[i] = dy[i] * (s * (1.0f + v * (1.0f - s)));
+    }
+}
+
+__global__ void add_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] += src[i];
+}
+
+// strided copy / add of a column block: dst[r][dc + c] (=|+=) src[r][sc + c]
+__global__ void copy_cols_kernel(float* __restrict__ dst, int64_t ldd, int dc, const float* __restrict__ src,
+                                 int64_t lds_, int sc, int64_t rows, int cols, int add) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        const float v = src[r * lds_ + sc + c];
+        float* d = dst + r * ldd + dc + c;
+        *d = add ? *d + v : v;
+    }
+}
+
+// inverted dropout in place.  spatial: one mask value per (sample, channel) of a
+// [samples][wlen][cols] stack; otherwise per element.  ld = row stride, cols = row width.
+__global__ void dropout_kernel(float* __restrict__ x, int64_t rows, int cols, int64_t ld, int wlen_spatial,
+                               unsigned seed, unsigned stream, unsigned thr, float scale) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        const unsigned idx = wlen_spatial ? (unsigned)((r / wlen_spatial) * cols + c) : (unsigned)i;
+        float* d = x + r * ld + c;
+        *d = hash_u32(seed, stream, idx) >= thr ? *d * scale : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------ embedding
+
+// x[r][c] = E[tok[r]][c] + P[r % wlen][c]                       (model.py:157-158)
+__global__ void embed_fwd_kernel(const uint8_t* __restrict__ tok, const float* __restrict__ E,
+                                 const float* __restrict__ P, float* __restrict__ x, int64_t rows, int wlen) {
+    const int64_t total = rows * 64;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i >> 6;
+        const int c = (int)(i & 63);
+        int t = tok[r];
+        t = t > 20 ? 20 : t;
+        x[i] = E[t * 64 + c] + P[(r % wlen) * 64 + c];
+    }
+}
+
+// dE[tok[r]][c] += dx[r][c];  dP[r % wlen][c] += dx[r][c].  Each block first sums its rows
+// per (code / position) in LDS, then issues one atomic per touched table entry.
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const uint8_t* __restrict__ tok, const float* __restrict__ dx,
+                                                        float* __restrict__ dE, float* __restrict__ dP,
+                                                        int64_t rows, int wlen, int rows_per_block) {
+    __shared__ float sE[21 * 64];
+    __shared__ float sP[51 * 64];
+    for (int i = threadIdx.x; i < 21 * 64; i += 256) sE[i] = 0.f;
+    for (int i = threadIdx.x; i < 51 * 64; i += 256) sP[i] = 0.f;
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(rows, r0 + rows_per_block);
+    const int c = threadIdx.x & 63;
+    for (int64_t r = r0 + (threadIdx.x >> 6); r < r1; r += 4) {
+        int t = tok[r];
+        t = t > 20 ? 20 : t;
+        const float g = dx[r * 64 + c];
+        atomicAdd(&sE[t * 64 + c], g);
+        atomicAdd(&sP[(int)(r % wlen) * 64 + c], g);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 21 * 64; i += 256)
+        if (sE[i] != 0.f) atomicAdd(dE + i, sE[i]);
+    for (int i = threadIdx.x; i < wlen * 64; i += 256)
+        if (sP[i] != 0.f) atomicAdd(dP + i, sP[i]);
+}
+
+// ------------------------------------------------------------------------------------ BatchNorm (training)
+
+// stats[c] += sum_r x[r][c]; stats[C + c] += sum_r x[r][c]^2.  block (64, 4), C <= 512
+__global__ __launch_bounds__(256) void colsum2_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                      int64_t rows, int cols, int64_t ld, float* __restrict__ stats,
+                                                      int rows_per_block) {
+    // with y == nullptr: sums of x and x*x; otherwise sums of x and x*y
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = min(rows, r0 + rows_per_block);
+    for (int c = blockIdx.x * 64 + (threadIdx.x & 63); c < cols; c += gridDim.x * 64) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int64_t r = r0 + (threadIdx.x >> 6); r < r1; r += 4) {
+            const float v = x[r * ld + c];
+            s1 += v;
+            s2 += v * (y ? y[r * ld + c] : v);
+        }
+        atomicAdd(stats + c, s1);
+        atomicAdd(stats + cols + c, s2);
+    }
+}
+
+// from the column sums: mean, inv = rsqrt(var + eps); moving stats <- 0.99*old + 0.01*batch
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int cols, float inv_rows, float* __restrict__ mean_inv,
+                                   const float* __restrict__ mov_mean, const float* __restrict__ mov_var,
+                                   float* __restrict__ new_mean, float* __restrict__ new_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    const float mu = stats[c] * inv_rows;
+    float var = stats[cols + c] * inv_rows - mu * mu;
+    var = var < 0.f ? 0.f : var;
+    mean_inv[c] = mu;
+    mean_inv[cols + c] = rsqrtf(var + 1e-3f);
+    new_mean[c] = 0.99f * mov_mean[c] + 0.01f * mu;
+    new_var[c] = 0.99f * mov_var[c] + 0.01f * var;
+}
+
+// z = (y - mean) * inv * gamma + beta
+__global__ void bn_fwd_kernel(const float* __restrict__ y, float* __restrict__ z, int64_t rows, int cols,
+                              const float* __restrict__ mean_inv, const float* __restrict__ gamma,
+                              const float* __restrict__ beta, int64_t ldz, int z_col_off) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        z[r * ldz + z_col_off + c] = (y[i] - mean_inv[c]) * mean_inv[cols + c] * gamma[c] + beta[c];
+    }
+}
+
+// sums[c] += sum_r dz[r][c]; sums[C+c] += sum_r dz[r][c] * xhat[r][c]   (xhat from y, mean, inv)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, int64_t lddz, int dz_col_off,
+                                                            const float* __restrict__ y, int64_t rows, int cols,
+                                                            const float* __restrict__ mean_inv, float* __restrict__ sums,
+                                                            int rows_per_block) {
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = min(rows, r0 + rows_per_block);
+    for (int c = blockIdx.x * 64 + (threadIdx.x & 63); c < cols; c += gridDim.x * 64) {
+        const float mu = mean_inv[c], inv = mean_inv[cols + c];
+        float s1 = 0.f, s2 = 0.f;
+        for (int64_t r = r0 + (threadIdx.x >> 6); r < r1; r += 4) {
+            const float g = dz[r * lddz + dz_col_off + c];
+            s1 += g;
+            s2 += g * (y[r * cols + c] - mu) * inv;
+        }
+        atomicAdd(sums + c, s1);
+        atomicAdd(sums + cols + c, s2);
+    }
+}
+
+// dy = gamma*inv * (dz - sum_dz/M - xhat * sum_dz_xhat/M); also dgamma += sum_dz_xhat, dbeta += sum_dz
+// (the parameter gradients are added by the first block only)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, int64_t lddz, int dz_col_off, const float* __restrict__ y,
+                                    float* __restrict__ dy, int64_t rows, int cols, const float* __restrict__ mean_inv,
+                                    const float* __restrict__ gamma, const float* __restrict__ sums, float inv_rows,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        const float inv = mean_inv[cols + c];
+        const float xh = (y[i] - mean_inv[c]) * inv;
+        dy[i] = gamma[c] * inv * (dz[r * lddz + dz_col_off + c] - sums[c] * inv_rows - xh * sums[cols + c] * inv_rows);
+        if (i < cols) {
+            atomicAdd(dgamma + c, sums[cols + c]);
+            atomicAdd(dbeta + c, sums[c]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ LayerNorm (64 features)
+
+// One wavefront per row: out = LN(a + b) * g + beta; saves xhat and inv for the backward.
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     const float* __restrict__ g, const float* __restrict__ beta,
+                                                     float* __restrict__ out, float* __restrict__ xhat,
+                                                     float* __restrict__ inv_out, int64_t rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float v = a[r * 64 + lane] + b[r * 64 + lane];
+    float s = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / 64.0f);
+    const float d = v - mean;
+    float q = d * d;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float inv = rsqrtf(q * (1.0f / 64.0f) + 1e-6f);
+    const float xh = d * inv;
+    xhat[r * 64 + lane] = xh;
+    out[r * 64 + lane] = xh * g[lane] + beta[lane];
+    if (lane == 0) inv_out[r] = inv;
+}
+
+// dsum = inv * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)); dg += sum dy*xhat; dbeta += sum dy
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+                                                     const float* __restrict__ inv_in, const float* __restrict__ g,
+                                                     float* __restrict__ dsum, float* __restrict__ dg,
+                                                     float* __restrict__ dbeta, int64_t rows, int rows_per_block) {
+    __shared__ float sg[4][64], sb[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(rows, r0 + rows_per_block);
+    const float gl = g[lane];
+    float ag = 0.f, ab = 0.f;
+    for (int64_t r = r0 + w; r < r1; r += 4) {
+        const float d = dy[r * 64 + lane], xh = xhat[r * 64 + lane];
+        const float dg_ = d * gl;
+        float s1 = dg_, s2 = dg_ * xh;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o);
+            s2 += __shfl_xor(s2, o);
+        }
+        dsum[r * 64 + lane] = inv_in[r] * (dg_ - s1 * (1.0f / 64.0f) - xh * s2 * (1.0f / 64.0f));
+        ag += d * xh;
+        ab += d;
+    }
+    sg[w][lane] = ag;
+    sb[w][lane] = ab;
+    __syncthreads();
+    if (w == 0) {
+        atomicAdd(dg + lane, sg[0][lane] + sg[1][lane] + sg[2][lane] + sg[3][lane]);
+        atomicAdd(dbeta + lane, sb[0][lane] + sb[1][lane] + sb[2][lane] + sb[3][lane]);
+    }
+}
+
+// ------------------------------------------------------------------------------------ attention (training)
+
+// One wavefront per (sample, head).  q,k,v,o: [rows][64] with head hd in columns 16hd..;
+// prob: [samples][4][wlen][wlen].   (model.py:67-82)
+__global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                      const float* __restrict__ v, float* __restrict__ o,
+                                                      float* __restrict__ prob, int wlen) {
+    __shared__ float sk[51][17], sv[51][17];
+    const int b = blockIdx.x >> 2, hd = blockIdx.x & 3, lane = threadIdx.x;
+    const int64_t base = (int64_t)b * wlen;
+    for (int i = lane; i < wlen * 16; i += 64) {
+        const int t = i >> 4, f = i & 15;
+        sk[t][f] = k[(base + t) * 64 + 16 * hd + f];
+        sv[t][f] = v[(base + t) * 64 + 16 * hd + f];
+    }
+    __syncthreads();
+    if (lane >= wlen) return;
+    float qr[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) qr[f] = q[(base + lane) * 64 + 16 * hd + f] * 0.25f;
+    float* pr = prob + (((int64_t)b * 4 + hd) * wlen + lane) * wlen;
+    float m = -3.0e38f;
+    for (int t = 0; t < wlen; ++t) {
+        float s = 0.f;
+#pragma unroll
+        for (int f = 0; f < 16; ++f) s = fmaf(qr[f], sk[t][f], s);
+        pr[t] = s;
+        m = fmaxf(m, s);
+    }
+    float den = 0.f;
+    for (int t = 0; t < wlen; ++t) {
+        const float e = __expf(pr[t] - m);
+        pr[t] = e;
+        den += e;
+    }
+    const float rd = 1.0f / den;
+    float acc[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) acc[f] = 0.f;
+    for (int t = 0; t < wlen; ++t) {
+        const float p_ = pr[t] * rd;
+        pr[t] = p_;
+#pragma unroll
+        for (int f = 0; f < 16; ++f) acc[f] = fmaf(p_, sv[t][f], acc[f]);
+    }
+#pragma unroll
+    for (int f = 0; f < 16; ++f) o[(base + lane) * 64 + 16 * hd + f] = acc[f];
+}
+
+// dq, dk, dv from do (all [rows][64], head columns), with the saved probabilities.
+__global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                      const float* __restrict__ v, const float* __restrict__ prob,
+                                                      const float* __restrict__ d_o, float* __restrict__ dq,
+                                                      float* __restrict__ dk, float* __restrict__ dv, int wlen) {
+    __shared__ float sq[51][17], sk[51][17], sv[51][17], sdo[51][17];
+    __shared__ float sp[51][52], sds[51][52];
+    const int b = blockIdx.x >> 2, hd = blockIdx.x & 3, lane = threadIdx.x;
+    const int64_t base = (int64_t)b * wlen;
+    for (int i = lane; i < wlen * 16; i += 64) {
+        const int t = i >> 4, f = i & 15;
+        const int64_t g = (base + t) * 64 + 16 * hd + f;
+        sq[t][f] = q[g];
+        sk[t][f] = k[g];
+        sv[t][f] = v[g];
+        sdo[t][f] = d_o[g];
+    }
+    const float* pb = prob + ((int64_t)b * 4 + hd) * wlen * wlen;
+    for (int i = lane; i < wlen * wlen; i += 64) sp[i / wlen][i % wlen] = pb[i];
+    __syncthreads();
+    if (lane < wlen) {   // query row `lane`: dP, dS and dQ
+        float dot = 0.f;
+        for (int t = 0; t < wlen; ++t) {
+            float dp = 0.f;
+#pragma unroll
+            for (int f = 0; f < 16; ++f) dp = fmaf(sdo[lane][f], sv[t][f], dp);
+            sds[lane][t] = dp;
+            dot = fmaf(dp, sp[lane][t], dot);
+        }
+        float acc[16];
+#pragma unroll
+        for (int f = 0; f < 16; ++f) acc[f] = 0.f;
+        for (int t = 0; t < wlen; ++t) {
+            const float ds = sp[lane][t] * (sds[lane][t] - dot);
+            sds[lane][t] = ds;
+#pragma unroll
+            for (int f = 0; f < 16; ++f) acc[f] = fmaf(ds, sk[t][f], acc[f]);
+        }
+#pragma unroll
+        for (int f = 0; f < 16; ++f) dq[(base + lane) * 64 + 16 * hd + f] = acc[f] * 0.25f;
+    }
+    __syncthreads();
+    if (lane < wlen) {   // key row `lane`: dK and dV
+        float ak[16], av[16];
+#pragma unroll
+        for (int f = 0; f < 16; ++f) ak[f] = av[f] = 0.f;
+        for (int i = 0; i < wlen; ++i) {
+            const float ds = sds[i][lane], p_ = sp[i][lane];
+#pragma unroll
+            for (int f = 0; f < 16; ++f) {
+                ak[f] = fmaf(ds, sq[i][f], ak[f]);
+                av[f] = fmaf(p_, sdo[i][f], av[f]);
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 16; ++f) {
+            dk[(base + lane) * 64 + 16 * hd + f] = ak[f] * 0.25f;
+            dv[(base + lane) * 64 + 16 * hd + f] = av[f];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ attention pooling
+
+// One wavefront per sample: a_t = tanh(x_t.w + b), alpha = softmax_t(a), out = sum alpha_t x_t.
+// Saves a_t and alpha_t ([samples][wlen] each).                        (model.py:176-182)
+__global__ __launch_bounds__(64) void pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ out,
+                                                      int64_t ldo, int col_off, float* __restrict__ a_save,
+                                                      float* __restrict__ alpha_save, int wlen) {
+    __shared__ float sa[64];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int64_t base = (int64_t)b * wlen;
+    float a = -3.0e38f;
+    if (lane < wlen) {
+        float s = bias[0];
+        for (int f = 0; f < 64; ++f) s = fmaf(x[(base + lane) * 64 + f], w[f], s);
+        a = tanhf(s);
+        a_save[base + lane] = a;
+    }
+    float m = a;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float e = lane < wlen ? __expf(a - m) : 0.f;
+    float den = e;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) den += __shfl_xor(den, o);
+    const float al = e / den;
+    sa[lane] = al;
+    if (lane < wlen) alpha_save[base + lane] = al;
+    __syncthreads();
+    float acc = 0.f;   // lane = feature
+    for (int t = 0; t < wlen; ++t) acc = fmaf(sa[t], x[(base + t) * 64 + lane], acc);
+    out[(int64_t)b * ldo + col_off + lane] = acc;
+}
+
+// dx_t = alpha_t*dout + dz_t*w with dz_t = alpha_t*(dalpha_t - sum alpha dalpha)*(1 - a_t^2),
+// dalpha_t = dout.x_t; dw += sum_t dz_t x_t; db += sum_t dz_t.
+__global__ __launch_bounds__(64) void pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ dout, int64_t ldd, int col_off,
+                                                      const float* __restrict__ a_save, const float* __restrict__ alpha_save,
+                                                      float* __restrict__ dx, float* __restrict__ dw,
+                                                      float* __restrict__ db, int wlen) {
+    __shared__ float sdz[64], sal[64], sdo[64];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int64_t base = (int64_t)b * wlen;
+    sdo[lane] = dout[(int64_t)b * ldd + col_off + lane];
+    __syncthreads();
+    float al = 0.f, dal = 0.f, a = 0.f;
+    if (lane < wlen) {
+        al = alpha_save[base + lane];
+        a = a_save[base + lane];
+        for (int f = 0; f < 64; ++f) dal = fmaf(sdo[f], x[(base + lane) * 64 + f], dal);
+    }
+    float dot = al * dal;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    const float dz = al * (dal - dot) * (1.0f - a * a);
+    sdz[lane] = lane < wlen ? dz : 0.f;
+    sal[lane] = al;
+    float dzs = lane < wlen ? dz : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dzs += __shfl_xor(dzs, o);
+    __syncthreads();
+    const float wl = w[lane], dol = sdo[lane];   // lane = feature
+    float gw = 0.f;
+    for (int t = 0; t < wlen; ++t) {
+        const float xv = x[(base + t) * 64 + lane];
+        dx[(base + t) * 64 + lane] = sal[t] * dol + sdz[t] * wl;
+        gw = fmaf(sdz[t], xv, gw);
+    }
+    atomicAdd(dw + lane, gw);
+    if (lane == 0) atomicAdd(db, dzs);
+}
+
+// ------------------------------------------------------------------------------------ head + loss
+
+// Per sample: logits = x.W + b (W [256][2]), softmax, class-balanced BCE (trainer.py:36-54),
+// d(logits); then dW, db (atomics) and dx.  One wavefront per sample.
+__global__ __launch_bounds__(64) void head_loss_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, const int32_t* __restrict__ labels,
+                                                       int64_t n, float n_global, float n_pos_global,
+                                                       float* __restrict__ proba, float* __restrict__ loss,
+                                                       float* __restrict__ dx, float* __restrict__ dW,
+                                                       float* __restrict__ db) {
+    const int64_t s = blockIdx.x;
+    const int lane = threadIdx.x;
+    float l0 = 0.f, l1 = 0.f;
+    float xv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        xv[i] = x[s * 256 + lane + 64 * i];
+        l0 = fmaf(xv[i], W[(lane + 64 * i) * 2], l0);
+        l1 = fmaf(xv[i], W[(lane + 64 * i) * 2 + 1], l1);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        l0 += __shfl_xor(l0, o);
+        l1 += __shfl_xor(l1, o);
+    }
+    l0 += bias[0];
+    l1 += bias[1];
+    const float m = fmaxf(l0, l1);
+    const float e0 = __expf(l0 - m), e1 = __expf(l1 - m);
+    const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+    const float eps = 1e-7f;
+    const int y = labels[s];
+    const float wt = y ? n_global / (2.0f * n_pos_global + eps) : n_global / (2.0f * (n_global - n_pos_global) + eps);
+    // keras binary_crossentropy over both softmax columns with the one-hot target.  For a
+    // 2-class softmax 1-p0 = p1, so the four log terms collapse to -2*log(c_y + eps) with
+    // c_y the clipped probability of the true class; this form is algebraically the same
+    // as the literal one and avoids its 1-p cancellation in fp32.
+    const float py = y ? p1 : p0;
+    const float cy = fminf(fmaxf(py, eps), 1.0f - eps);
+    const float bce = -2.0f * logf(cy + eps);
+    const float scale = wt / (n_global * 2.0f);
+    // d(scale*bce)/d(logit_i) = 2*scale * py/(cy+eps) * (p_i - [i == y]); zero where the clip is active
+    const float gy = (py > eps && py < 1.0f - eps) ? 2.0f * scale * py / (cy + eps) : 0.f;
+    const float d0 = gy * (p0 - (y ? 0.f : 1.f)), d1 = gy * (p1 - (y ? 1.f : 0.f));
+    if (lane == 0) {
+        proba[s * 2] = p0;
+        proba[s * 2 + 1] = p1;
+        atomicAdd(loss, scale * bce);
+        atomicAdd(db, d0);
+        atomicAdd(db + 1, d1);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = lane + 64 * i;
+        dx[s * 256 + f] = d0 * W[f * 2] + d1 * W[f * 2 + 1];
+        atomicAdd(dW + f * 2, d0 * xv[i]);
+        atomicAdd(dW + f * 2 + 1, d1 * xv[i]);
+    }
+}
+
+// ------------------------------------------------------------------------------------ optimiser
+
+// sum of squares of a tensor (for the l2 regulariser value) and g += 2*lambda*w
+__global__ void l2_kernel(const float* __restrict__ w, float* __restrict__ g, int64_t n, float lambda, float* __restrict__ loss) {
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = w[i];
+        g[i] += 2.0f * lambda * v;
+        s = fmaf(v, v, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(loss, lambda * s);
+}
+
+// tensorflow-addons AdamW: w -= wd*w, then keras Adam with lr_t = lr*sqrt(1-b2^t)/(1-b1^t).
+// mask[i] = 0 marks the BatchNorm moving statistics (not trained; overwritten from `stat`).
+__global__ void adamw_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, const uint8_t* __restrict__ trainable, const float* __restrict__ stat,
+                             int64_t n, float lr_t, float wd, float b1, float b2, float eps, float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (!trainable[i]) {
+            w[i] = stat[i];
+            continue;
+        }
+        const float gi = g[i] * gscale;
+        float wi = w[i];
+        wi -= wd * wi;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        w[i] = wi - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+// ------------------------------------------------------------------------------------ launchers
+
+static inline unsigned grid_for(int64_t n, int block = 256, int64_t cap = 256 * 16) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+hipError_t t_gemm(const GemmArgs& a, bool nt, hipStream_t st) {
+    if (a.m == 0) return hipSuccess;
+    if (a.cols % 64 != 0 || a.k % 8 != 0) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((a.m + 127) / 128), (unsigned)(a.cols / 64));
+    if (nt)
+        hipLaunchKernelGGL(tgemm_kernel<true>, grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(tgemm_kernel<false>, grid, dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t t_gemm_tn(GemmTnArgs a, hipStream_t st) {
+    if (a.m == 0) return hipSuccess;
+    if (a.n % 32 != 0) return hipErrorInvalidValue;
+    int64_t slabs = (a.m + 511) / 512;
+    if (slabs > 512) slabs = 512;
+    a.rows_per_slab = (a.m + slabs - 1) / slabs;
+    a.rows_per_slab += a.rows_per_slab & 1;   // even: the two half-waves alternate rows
+    slabs = (a.m + a.rows_per_slab - 1) / a.rows_per_slab;
+    dim3 grid((unsigned)((a.k + 31) / 32), (unsigned)(a.n / 32), (unsigned)slabs);
+    hipLaunchKernelGGL(tgemm_tn_kernel, grid, dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t t_swish_fwd(const float* a, float* y, int64_t n, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(swish_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, a, y, n);
+    return hipGetLastError();
+}
+hipError_t t_swish_bwd(const float* a, const float* dy, float* da, int64_t n, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(swish_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, a, dy, da, n);
+    return hipGetLastError();
+}
+hipError_t t_add(float* dst, const float* src, int64_t n, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, st, dst, src, n);
+    return hipGetLastError();
+}
+hipError_t t_copy_cols(float* dst, int64_t ldd, int dc, const float* src, int64_t lds_, int sc, int64_t rows,
+                       int cols, bool add, hipStream_t st) {
+    if (rows) hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, st, dst, ldd, dc, src, lds_, sc, rows, cols, add ? 1 : 0);
+    return hipGetLastError();
+}
+hipError_t t_dropout(float* x, int64_t rows, int cols, int64_t ld, int wlen_spatial, unsigned seed, unsigned stream,
+                     float rate, hipStream_t st) {
+    if (rate <= 0.f || rows == 0) return hipSuccess;
+    double t = (double)rate * 4294967296.0;
+    const unsigned thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, st, x, rows, cols, ld, wlen_spatial, seed,
+                       stream, thr, 1.0f / (1.0f - rate));
+    return hipGetLastError();
+}
+hipError_t t_embed_fwd(const uint8_t* tok, const float* E, const float* P, float* x, int64_t rows, int wlen, hipStream_t st) {
+    if (rows) hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for(rows * 64)), dim3(256), 0, st, tok, E, P, x, rows, wlen);
+    return hipGetLastError();
+}
+hipError_t t_embed_bwd(const uint8_t* tok, const float* dx, float* dE, float* dP, int64_t rows, int wlen, hipStream_t st) {
+    if (rows == 0) return hipSuccess;
+    const int rpb = 2048;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st, tok, dx, dE, dP, rows, wlen, rpb);
+    return hipGetLastError();
+}
+static inline int rows_per_block_for(int64_t rows) {
+    int64_t r = (rows + 255) / 256;
+    if (r < 64) r = 64;
+    return (int)r;
+}
+hipError_t t_colsum2(const float* x, const float* y, int64_t rows, int cols, float* stats, hipStream_t st) {
+    if (rows == 0) return hipSuccess;
+    const int rpb = rows_per_block_for(rows);
+    dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + rpb - 1) / rpb));
+    hipLaunchKernelGGL(colsum2_kernel, grid, dim3(256), 0, st, x, y, rows, cols, (int64_t)cols, stats, rpb);
+    return hipGetLastError();
+}
+hipError_t t_bn_finalize(const float* stats, int cols, int64_t rows, float* mean_inv, const float* mov_mean,
+                         const float* mov_var, float* new_mean, float* new_var, hipStream_t st) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, stats, cols, 1.0f / (float)rows,
+                       mean_inv, mov_mean, mov_var, new_mean, new_var);
+    return hipGetLastError();
+}
+hipError_t t_bn_fwd(const float* y, float* z, int64_t rows, int cols, const float* mean_inv, const float* gamma,
+                    const float* beta, int64_t ldz, int z_col_off, hipStream_t st) {
+    if (rows) hipLaunchKernelGGL(bn_fwd_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, st, y, z, rows, cols, mean_inv, gamma, beta, ldz, z_col_off);
+    return hipGetLastError();
+}
+hipError_t t_bn_bwd(const float* dz, int64_t lddz, int dz_col_off, const float* y, float* dy, int64_t rows, int cols,
+                    const float* mean_inv, const float* gamma, float* sums, float* dgamma, float* dbeta, hipStream_t st) {
+    if (rows == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(sums, 0, 2 * cols * sizeof(float), st);
+    if (e != hipSuccess) return e;
+    const int rpb = rows_per_block_for(rows);
+    dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + rpb - 1) / rpb));
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, st, dz, lddz, dz_col_off, y, rows, cols, mean_inv, sums, rpb);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, st, dz, lddz, dz_col_off, y, dy, rows,
+                       cols, mean_inv, gamma, sums, 1.0f / (float)rows, dgamma, dbeta);
+    return hipGetLastError();
+}
+hipError_t t_ln_fwd(const float* a, const float* b, const float* g, const float* beta, float* out, float* xhat,
+                    float* inv, int64_t rows, hipStream_t st) {
+    if (rows) hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a, b, g, beta, out, xhat, inv, rows);
+    return hipGetLastError();
+}
+hipError_t t_ln_bwd(const float* dy, const float* xhat, const float* inv, const float* g, float* dsum, float* dg,
+                    float* dbeta, int64_t rows, hipStream_t st) {
+    if (rows == 0) return hipSuccess;
+    const int rpb = rows_per_block_for(rows);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st, dy, xhat, inv, g, dsum, dg, dbeta, rows, rpb);
+    return hipGetLastError();
+}
+hipError_t t_attn_fwd(const float* q, const float* k, const float* v, float* o, float* prob, int64_t samples, int wlen, hipStream_t st) {
+    if (samples) hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(samples * 4)), dim3(64), 0, st, q, k, v, o, prob, wlen);
+    return hipGetLastError();
+}
+hipError_t t_attn_bwd(const float* q, const float* k, const float* v, const float* prob, const float* d_o, float* dq,
+                      float* dk, float* dv, int64_t samples, int wlen, hipStream_t st) {
+    if (samples) hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(samples * 4)), dim3(64), 0, st, q, k, v, prob, d_o, dq, dk, dv, wlen);
+    return hipGetLastError();
+}
+hipError_t t_pool_fwd(const float* x, const float* w, const float* bias, float* out, int64_t ldo, int col_off, float* a_save,
+                      float* alpha_save, int64_t samples, int wlen, hipStream_t st) {
+    if (samples) hipLaunchKernelGGL(pool_fwd_kernel, dim3((unsigned)samples), dim3(64), 0, st, x, w, bias, out, ldo, col_off, a_save, alpha_save, wlen);
+    return hipGetLastError();
+}
+hipError_t t_pool_bwd(const float* x, const float* w, const float* dout, int64_t ldd, int col_off, const float* a_save,
+                      const float* alpha_save, float* dx, float* dw, float* db, int64_t samples, int wlen, hipStream_t st) {
+    if (samples) hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)samples), dim3(64), 0, st, x, w, dout, ldd, col_off, a_save, alpha_save, dx, dw, db, wlen);
+    return hipGetLastError();
+}
+hipError_t t_head_loss(const float* x, const float* W, const float* bias, const int32_t* labels, int64_t n, float n_global,
+                       float n_pos_global, float* proba, float* loss, float* dx, float* dW, float* db, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(head_loss_kernel, dim3((unsigned)n), dim3(64), 0, st, x, W, bias, labels, n, n_global, n_pos_global, proba, loss, dx, dW, db);
+    return hipGetLastError();
+}
+hipError_t t_l2(const float* w, float* g, int64_t n, float lambda, float* loss, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(l2_kernel, dim3(grid_for(n, 256, 64)), dim3(256), 0, st, w, g, n, lambda, loss);
+    return hipGetLastError();
+}
+hipError_t t_adamw(float* w, const float* g, float* m, float* v, const uint8_t* trainable, const float* stat, int64_t n,
+                   float lr_t, float wd, float b1, float b2, float eps, float gscale, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, st, w, g, m, v, trainable, stat, n, lr_t, wd, b1, b2, eps, gscale);
+    return hipGetLastError();
+}
+
+}  // namespace dptm

@@ -145,6 +145,60 @@ int64_t dptm_chunk_sites(const dptm_handle* h);
 
 const char* dptm_last_error(void);
 
+/* ------------------------------------------------------------------------------------
+ * Training step.  Replaces what model.fit runs per batch in the reference
+ *   pred/train_PTM/trainer.py:304-309  compile(optimizer=AdamW(lr, weight_decay), loss=focal_loss)
+ *   pred/train_PTM/trainer.py:332-339  model.fit(...)   (forward in training mode, loss of
+ *                                      trainer.py:36-54, backward, optimizer update)
+ * for the graph of model.py:143-210.  One trainer per GPU (data-parallel replica); the
+ * caller all-reduces the flat gradient buffer between forward_backward and apply.
+ * ------------------------------------------------------------------------------------ */
+typedef struct dptm_trainer dptm_trainer;
+
+typedef struct dptm_train_opts {
+    uint32_t seed;          /* dropout stream seed for this step (and rank) */
+    float rate_embed;       /* SpatialDropout1D after the position embedding (model.py:159: 1e-4) */
+    float rate_conv;        /* SpatialDropout1D in the conv block (model.py:136: 0.3) */
+    float rate_tb;          /* TransformerBlock dropouts (model.py:94,108-109: 0.1) */
+    float rate_dense;       /* Dropout on struct/ESM/merged/trunk (model.py:189,193,198,202: 0.3) */
+    int64_t n_global;       /* N of trainer.py:39 over the whole (global) batch, >= 1 */
+    int64_t n_pos_global;   /* N_pos of trainer.py:40 over the whole batch */
+    float l2;               /* kernel regulariser factor (config.py:53: 1e-4); 0 disables */
+    float l2_scale;         /* multiplies the regulariser value and gradient (1/world for DP) */
+} dptm_train_opts;
+
+/* weights: the same fp32 blob dptm_create takes.  max_batch bounds the sites per call. */
+int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spec, int device,
+                        int64_t max_batch, dptm_trainer** out);
+void dptm_trainer_destroy(dptm_trainer* t);
+
+/* Forward (training mode) + loss + backward for n sites.  Inputs are DEVICE pointers laid
+ * out as for dptm_score_device; labels int32 [n] (0/1 = argmax of the one-hot y_true,
+ * trainer.py:38).  Gradients land in the trainer's flat gradient buffer.  If loss_out (a
+ * HOST pointer) is not NULL the call waits and stores this replica's loss share there. */
+int dptm_trainer_forward_backward(dptm_trainer* t, const uint8_t* tok21, const uint8_t* tok33,
+                                  const uint8_t* tok51, const float* strct, const float* esm,
+                                  const int32_t* labels, int64_t n, const dptm_train_opts* opts,
+                                  float* loss_out, void* stream);
+
+/* Device address and length (floats) of the flat gradient buffer: one contiguous fp32
+ * array holding every tensor's gradient (256-byte aligned slots, padding stays zero), the
+ * single bucket a data-parallel job all-reduces per step. */
+int dptm_trainer_grad_buffer(dptm_trainer* t, float** dev_ptr, int64_t* count);
+int64_t dptm_trainer_param_floats(const dptm_trainer* t);
+
+/* tensorflow-addons AdamW (trainer.py:305-306): var -= weight_decay*var, then Adam with
+ * beta1 0.9, beta2 0.999, eps 1e-7 on grad_scale * gradient; BatchNorm moving statistics
+ * take the values computed by the last forward (momentum 0.99). */
+int dptm_trainer_apply(dptm_trainer* t, float lr, float weight_decay, float grad_scale, void* stream);
+
+/* Host copies in the canonical blob order (dptm_weight_count floats); they wait for the GPU. */
+int dptm_trainer_get_weights(dptm_trainer* t, float* host_out);
+int dptm_trainer_get_grads(dptm_trainer* t, float* host_out);
+int dptm_trainer_get_proba(dptm_trainer* t, float* host_out, int64_t n);
+const char* dptm_trainer_last_error(void);
+
+
 #ifdef __cplusplus
 }
 #endif

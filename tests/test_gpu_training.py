@@ -1,0 +1,92 @@
+"""The native training step (C ABI dptm_trainer_*) against the torch-autograd restatement
+(oracle/train_ref.py, fp64).  Tolerances: gradients within 2e-4 of the largest entry of
+each tensor (fp32 kernels with atomics vs an fp64 reference), loss 1e-4 relative."""
+import numpy as np
+import pytest
+
+from deepptmpred_amd import _native, spec
+from oracle.train_ref import TrainRef
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_batch(x, y):
+    import torch
+    dev = torch.device("cuda:0")
+    d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in x]
+    lab = torch.from_numpy(np.asarray(y, dtype=np.int32)).to(dev)
+    return d, lab
+
+
+def _opts(seed, rates, y, l2=1e-4):
+    o = _native.TrainOpts()
+    o.seed = seed
+    o.rate_embed, o.rate_conv, o.rate_tb, o.rate_dense = rates
+    o.n_global = len(y)
+    o.n_pos_global = int(np.sum(y))
+    o.l2 = l2
+    o.l2_scale = 1.0
+    return o
+
+
+def _compare_grads(got_blob, want, label):
+    got = spec.unpack_blob(got_blob)
+    worst, bad = 0.0, []
+    for k, g in want.items():
+        scale = max(np.abs(g).max(), 1e-3)  # biases in front of a BatchNorm and the key bias have zero true gradient
+        err = np.abs(got[k] - g).max() / scale
+        worst = max(worst, err)
+        if err >= 2e-4:
+            bad.append(f"{k}: {err:.3e} (max |g| {scale:.3e})")
+    assert not bad, f"{label}: gradients off: " + "; ".join(bad)
+    return worst
+
+
+@pytest.mark.parametrize("rates", [(0.0, 0.0, 0.0, 0.0), (1e-4, 0.3, 0.1, 0.3)])
+def test_gradients_match_autograd(rates):
+    import torch
+    w = spec.synthetic_weights(7)
+    n = 48
+    x = spec.synthetic_inputs(n, 321)
+    y = (np.random.default_rng(5).random(n) < 0.25).astype(np.int64)
+    ref = TrainRef(w)
+    rd = dict(zip(("embed", "conv", "tb", "dense"), rates))
+    loss_ref, g_ref = ref.step(x, y, lr=5e-4, weight_decay=1e-4, seed=99, rates=rd)
+
+    tr = _native.Trainer(spec.pack_blob(w), max_batch=64)
+    d, lab = _device_batch(x, y)
+    loss = tr.forward_backward(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+                               lab.data_ptr(), n, _opts(99, rates, y))
+    torch.cuda.synchronize()
+    assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref)), (loss, loss_ref)
+    worst = _compare_grads(tr.get_grads(), g_ref, f"rates={rates}")
+    print("worst relative gradient error", worst)
+    # optimizer step: weights (and BatchNorm moving statistics) after AdamW
+    tr.apply(5e-4, 1e-4)
+    got = spec.unpack_blob(tr.get_weights())
+    for k, v in ref.weights().items():
+        assert np.abs(got[k] - v).max() < 2e-5 * max(1.0, np.abs(v).max()), k
+    tr.close()
+
+
+def test_two_steps_track_reference():
+    import torch
+    w = spec.synthetic_weights(101)
+    ref = TrainRef(w)
+    tr = _native.Trainer(spec.pack_blob(w), max_batch=32)
+    rates = (0.0, 0.0, 0.0, 0.0)
+    for step in range(2):
+        n = 32
+        x = spec.synthetic_inputs(n, 700 + step)
+        y = (np.random.default_rng(step).random(n) < 0.3).astype(np.int64)
+        loss_ref, _ = ref.step(x, y, seed=step, rates=dict(embed=0, conv=0, tb=0, dense=0))
+        d, lab = _device_batch(x, y)
+        loss = tr.forward_backward(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
+                                   d[4].data_ptr(), lab.data_ptr(), n, _opts(step, rates, y))
+        torch.cuda.synchronize()
+        assert abs(loss - loss_ref) < 5e-5 * max(1.0, abs(loss_ref)), (step, loss, loss_ref)
+        tr.apply(5e-4, 1e-4)
+    got = spec.unpack_blob(tr.get_weights())
+    for k, v in ref.weights().items():
+        assert np.abs(got[k] - v).max() < 1e-4 * max(1.0, np.abs(v).max()), k
+    tr.close()
