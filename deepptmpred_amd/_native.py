@@ -136,7 +136,7 @@ def load_library() -> C.CDLL:
     lib.dptm_trainer_param_floats.restype = C.c_int64
     lib.dptm_trainer_param_floats.argtypes = [vp]
     lib.dptm_trainer_apply.restype = C.c_int
-    lib.dptm_trainer_apply.argtypes = [vp, C.c_float, C.c_float, C.c_float, vp]
+    lib.dptm_trainer_apply.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     for name in ("dptm_trainer_get_weights", "dptm_trainer_get_grads"):
         getattr(lib, name).restype = C.c_int
         getattr(lib, name).argtypes = [vp, f32p]
@@ -294,8 +294,10 @@ class Trainer:
                  "dptm_trainer_grad_buffer")
         return int(p.value), int(n.value)
 
-    def apply(self, lr: float, weight_decay: float, grad_scale: float = 1.0, stream=0) -> None:
-        rc = self._lib.dptm_trainer_apply(self._h, lr, weight_decay, grad_scale, C.c_void_p(stream or None))
+    def apply(self, lr: float, weight_decay: float, grad_scale: float = 1.0, stat_scale: float = 1.0,
+              stream=0) -> None:
+        rc = self._lib.dptm_trainer_apply(self._h, lr, weight_decay, grad_scale, stat_scale,
+                                          C.c_void_p(stream or None))
         _check_t(self._lib, rc, "dptm_trainer_apply")
 
     def get_weights(self) -> np.ndarray:

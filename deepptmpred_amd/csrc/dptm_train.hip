@@ -111,7 +111,7 @@ struct dptm_trainer {
     hipStream_t stream = nullptr;
     int64_t max_batch = 0;
     PMap pm;
-    float *W = nullptr, *G = nullptr, *M = nullptr, *V = nullptr, *S = nullptr;  // weights, grads, Adam moments, new BN stats
+    float *W = nullptr, *G = nullptr, *M = nullptr, *V = nullptr;  // weights, grads (+ batch BN stats), Adam moments
     uint8_t* trainable = nullptr;
     Arena arena;
     BranchAct ba[3];
@@ -187,8 +187,8 @@ int bn_train_fwd(const Ctx& c, const float* y, float* z, int64_t ldz, int zoff, 
     dptm_trainer* t = c.t;
     T_TRY(hipMemsetAsync(t->bnstat, 0, 2 * cols * sizeof(float), c.st));
     T_TRY(t_colsum2(y, nullptr, rows, cols, t->bnstat, c.st));
-    T_TRY(t_bn_finalize(t->bnstat, cols, rows, mi, c.w(bn.mean), c.w(bn.var), t->S + t->pm.t[bn.mean].off,
-                        t->S + t->pm.t[bn.var].off, c.st));
+    // the batch statistics ride in the (otherwise unused) moving-stat slots of the gradient buffer
+    T_TRY(t_bn_finalize(t->bnstat, cols, rows, mi, c.g(bn.mean), c.g(bn.var), c.st));
     T_TRY(t_bn_fwd(y, z, rows, cols, mi, c.w(bn.gamma), c.w(bn.beta), ldz, zoff, c.st));
     return DPTM_OK;
 }
@@ -339,7 +339,7 @@ void dptm_trainer_destroy(dptm_trainer* t) {
     if (!t) return;
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
-    void* bufs[] = {t->W, t->G, t->M, t->V, t->S, t->trainable, t->arena.base};
+    void* bufs[] = {t->W, t->G, t->M, t->V, t->trainable, t->arena.base};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (t->stream) (void)hipStreamDestroy(t->stream);
@@ -372,7 +372,7 @@ int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spe
     const size_t pb = (size_t)t->pm.total * sizeof(float);
     if (hipMalloc((void**)&t->W, pb) != hipSuccess || hipMalloc((void**)&t->G, pb) != hipSuccess ||
         hipMalloc((void**)&t->M, pb) != hipSuccess || hipMalloc((void**)&t->V, pb) != hipSuccess ||
-        hipMalloc((void**)&t->S, pb) != hipSuccess || hipMalloc((void**)&t->trainable, (size_t)t->pm.total) != hipSuccess)
+        hipMalloc((void**)&t->trainable, (size_t)t->pm.total) != hipSuccess)
         return bail(DPTM_ENOMEM, "dptm_trainer_create: parameter buffers");
     std::vector<float> host((size_t)t->pm.total, 0.0f);
     std::vector<uint8_t> tr((size_t)t->pm.total, 0);
@@ -382,7 +382,6 @@ int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spe
         if (x.trainable) std::memset(tr.data() + x.off, 1, (size_t)x.size);
     }
     if (hipMemcpy(t->W, host.data(), pb, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(t->S, host.data(), pb, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(t->trainable, tr.data(), tr.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(t->G, 0, pb) != hipSuccess || hipMemset(t->M, 0, pb) != hipSuccess || hipMemset(t->V, 0, pb) != hipSuccess)
         return bail(DPTM_EHIP, "dptm_trainer_create: parameter upload");
@@ -500,14 +499,14 @@ int dptm_trainer_forward_backward(dptm_trainer* t, const uint8_t* tok21, const u
 }
 
 // tensorflow-addons AdamW step on the flat buffers (gradients are multiplied by grad_scale first).
-int dptm_trainer_apply(dptm_trainer* t, float lr, float weight_decay, float grad_scale, void* stream) {
+int dptm_trainer_apply(dptm_trainer* t, float lr, float weight_decay, float grad_scale, float stat_scale, void* stream) {
     if (!t) return tfail(DPTM_EINVAL, "dptm_trainer_apply: NULL trainer");
     T_TRY(hipSetDevice(t->device));
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : t->stream;
     t->step += 1;
     const double b1 = 0.9, b2 = 0.999;
     const float lr_t = (float)(lr * std::sqrt(1.0 - std::pow(b2, (double)t->step)) / (1.0 - std::pow(b1, (double)t->step)));
-    T_TRY(t_adamw(t->W, t->G, t->M, t->V, t->trainable, t->S, t->pm.total, lr_t, weight_decay, (float)b1, (float)b2, 1e-7f,
+    T_TRY(t_adamw(t->W, t->G, t->M, t->V, t->trainable, stat_scale, t->pm.total, lr_t, weight_decay, (float)b1, (float)b2, 1e-7f,
                   grad_scale, st));
     return DPTM_OK;
 }

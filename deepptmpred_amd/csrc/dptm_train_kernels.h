@@ -53,8 +53,8 @@ hipError_t t_dropout(float* x, int64_t rows, int cols, int64_t ld, int wlen_spat
 hipError_t t_embed_fwd(const uint8_t* tok, const float* E, const float* P, float* x, int64_t rows, int wlen, hipStream_t st);
 hipError_t t_embed_bwd(const uint8_t* tok, const float* dx, float* dE, float* dP, int64_t rows, int wlen, hipStream_t st);
 hipError_t t_colsum2(const float* x, const float* y, int64_t rows, int cols, float* stats, hipStream_t st);
-hipError_t t_bn_finalize(const float* stats, int cols, int64_t rows, float* mean_inv, const float* mov_mean,
-                         const float* mov_var, float* new_mean, float* new_var, hipStream_t st);
+hipError_t t_bn_finalize(const float* stats, int cols, int64_t rows, float* mean_inv, float* batch_mean,
+                         float* batch_var, hipStream_t st);
 hipError_t t_bn_fwd(const float* y, float* z, int64_t rows, int cols, const float* mean_inv, const float* gamma,
                     const float* beta, int64_t ldz, int z_col_off, hipStream_t st);
 hipError_t t_bn_bwd(const float* dz, int64_t lddz, int dz_col_off, const float* y, float* dy, int64_t rows, int cols,
@@ -73,7 +73,7 @@ hipError_t t_pool_bwd(const float* x, const float* w, const float* dout, int64_t
 hipError_t t_head_loss(const float* x, const float* W, const float* bias, const int32_t* labels, int64_t n, float n_global,
                        float n_pos_global, float* proba, float* loss, float* dx, float* dW, float* db, hipStream_t st);
 hipError_t t_l2(const float* w, float* g, int64_t n, float lambda, float* loss, hipStream_t st);
-hipError_t t_adamw(float* w, const float* g, float* m, float* v, const uint8_t* trainable, const float* stat, int64_t n,
+hipError_t t_adamw(float* w, const float* g, float* m, float* v, const uint8_t* trainable, float stat_scale, int64_t n,
                    float lr_t, float wd, float b1, float b2, float eps, float gscale, hipStream_t st);
 
 }  // namespace dptm

@@ -245,10 +245,10 @@ __global__ __launch_bounds__(256) void colsum2_kernel(const float* __restrict__ 
     }
 }
 
-// from the column sums: mean, inv = rsqrt(var + eps); moving stats <- 0.99*old + 0.01*batch
+// from the column sums: mean, inv = rsqrt(var + eps); the batch mean and (biased) variance
+// are also left in batch_mean / batch_var for the moving-statistics update
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, int cols, float inv_rows, float* __restrict__ mean_inv,
-                                   const float* __restrict__ mov_mean, const float* __restrict__ mov_var,
-                                   float* __restrict__ new_mean, float* __restrict__ new_var) {
+                                   float* __restrict__ batch_mean, float* __restrict__ batch_var) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= cols) return;
     const float mu = stats[c] * inv_rows;
@@ -256,8 +256,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int cols, fl
     var = var < 0.f ? 0.f : var;
     mean_inv[c] = mu;
     mean_inv[cols + c] = rsqrtf(var + 1e-3f);
-    new_mean[c] = 0.99f * mov_mean[c] + 0.01f * mu;
-    new_var[c] = 0.99f * mov_var[c] + 0.01f * var;
+    batch_mean[c] = mu;
+    batch_var[c] = var;
 }
 
 // z = (y - mean) * inv * gamma + beta
@@ -631,13 +631,14 @@ __global__ void l2_kernel(const float* __restrict__ w, float* __restrict__ g, in
 }
 
 // tensorflow-addons AdamW: w -= wd*w, then keras Adam with lr_t = lr*sqrt(1-b2^t)/(1-b1^t).
-// mask[i] = 0 marks the BatchNorm moving statistics (not trained; overwritten from `stat`).
+// trainable[i] = 0 marks the BatchNorm moving statistics: their slot of the gradient buffer
+// holds the batch statistic (summed over replicas), and they move with momentum 0.99.
 __global__ void adamw_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
-                             float* __restrict__ v, const uint8_t* __restrict__ trainable, const float* __restrict__ stat,
+                             float* __restrict__ v, const uint8_t* __restrict__ trainable, float stat_scale,
                              int64_t n, float lr_t, float wd, float b1, float b2, float eps, float gscale) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         if (!trainable[i]) {
-            w[i] = stat[i];
+            w[i] = 0.99f * w[i] + 0.01f * (g[i] * stat_scale);
             continue;
         }
         const float gi = g[i] * gscale;
@@ -732,10 +733,10 @@ hipError_t t_colsum2(const float* x, const float* y, int64_t rows, int cols, flo
     hipLaunchKernelGGL(colsum2_kernel, grid, dim3(256), 0, st, x, y, rows, cols, (int64_t)cols, stats, rpb);
     return hipGetLastError();
 }
-hipError_t t_bn_finalize(const float* stats, int cols, int64_t rows, float* mean_inv, const float* mov_mean,
-                         const float* mov_var, float* new_mean, float* new_var, hipStream_t st) {
+hipError_t t_bn_finalize(const float* stats, int cols, int64_t rows, float* mean_inv, float* batch_mean,
+                         float* batch_var, hipStream_t st) {
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, stats, cols, 1.0f / (float)rows,
-                       mean_inv, mov_mean, mov_var, new_mean, new_var);
+                       mean_inv, batch_mean, batch_var);
     return hipGetLastError();
 }
 hipError_t t_bn_fwd(const float* y, float* z, int64_t rows, int cols, const float* mean_inv, const float* gamma,
@@ -795,9 +796,9 @@ hipError_t t_l2(const float* w, float* g, int64_t n, float lambda, float* loss, 
     if (n) hipLaunchKernelGGL(l2_kernel, dim3(grid_for(n, 256, 64)), dim3(256), 0, st, w, g, n, lambda, loss);
     return hipGetLastError();
 }
-hipError_t t_adamw(float* w, const float* g, float* m, float* v, const uint8_t* trainable, const float* stat, int64_t n,
+hipError_t t_adamw(float* w, const float* g, float* m, float* v, const uint8_t* trainable, float stat_scale, int64_t n,
                    float lr_t, float wd, float b1, float b2, float eps, float gscale, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, st, w, g, m, v, trainable, stat, n, lr_t, wd, b1, b2, eps, gscale);
+    if (n) hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, st, w, g, m, v, trainable, stat_scale, n, lr_t, wd, b1, b2, eps, gscale);
     return hipGetLastError();
 }
 

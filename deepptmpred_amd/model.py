@@ -90,6 +90,9 @@ class Model:
             raise ValueError("predict: all five inputs must have the same number of rows")
         if n == 0:
             return np.zeros((0, self.spec.n_classes), dtype=np.float32)
+        if getattr(self, "_dirty", False):      # weights were trained since the last scorer was built
+            self._pull_trained_weights()
+            self._dirty = False
         return self.scorer.score(toks[0], toks[1], toks[2], st, esm)
 
     def __call__(self, x, training=False):
@@ -115,7 +118,68 @@ class Model:
             return np.zeros((0, self.spec.n_classes), dtype=np.float32)
         return self.scorer.score_protein(codes, table, pos.astype(np.int32), st)
 
+    # -- training (trainer.py:304-339)
+    def compile(self, optimizer=None, loss=None, metrics=None, **_ignored) -> None:
+        """``model.compile(optimizer=AdamW(...), loss=..., metrics=...)`` (trainer.py:304-309).
+        Only the optimizer's ``learning_rate`` and ``weight_decay`` are used; the loss is
+        always the class-balanced cross-entropy of trainer.py:36-54, built into the kernels."""
+        from .training import AdamW
+        lr = getattr(optimizer, "learning_rate", 5e-4) if optimizer is not None else 5e-4
+        wd = getattr(optimizer, "weight_decay", 1e-4) if optimizer is not None else 1e-4
+        self._optimizer = AdamW(float(lr), float(wd))
+        self._dp = None
+
+    def _trainer(self, batch_size: int):
+        from .training import DataParallelTrainer, DropoutRates, NativeBackend
+        if getattr(self, "_optimizer", None) is None:
+            raise RuntimeError("call compile() before training")
+        if getattr(self, "_dp", None) is None or self._dp_batch < batch_size:
+            if getattr(self, "_dp", None) is not None:
+                self._pull_trained_weights()
+                self._dp.backend.close()
+            backend = NativeBackend(self._weights, self.spec, self.device, max_batch=batch_size)
+            self._dp = DataParallelTrainer(backend, self._optimizer,
+                                           DropoutRates(self.spec.weight_decay, self.spec.dropout_rate, 0.1,
+                                                        self.spec.dropout_rate), l2=self.spec.weight_decay)
+            self._dp_batch = batch_size
+        return self._dp
+
+    def _pull_trained_weights(self) -> None:
+        if getattr(self, "_dp", None) is not None:
+            self._weights = {k: np.asarray(v, dtype=np.float32) for k, v in self._dp.backend.weights().items()}
+            self._blob = pack_blob(self._weights, self.spec)
+            self.close()
+
+    def train_on_batch(self, x, y) -> float:
+        n = len(np.asarray(y))
+        loss = self._trainer(n).train_on_batch(x, y)
+        self._dirty = True
+        return loss
+
+    def fit(self, x, y, batch_size: int = 64, epochs: int = 1, validation_data=None, callbacks=None,
+            verbose=1, shuffle: bool = True, **_ignored):
+        """``model.fit`` (trainer.py:332-339).  Of the reference's callbacks only a learning-rate
+        schedule is honoured: any callback object with a ``schedule(epoch, lr)`` attribute
+        (keras ``LearningRateScheduler``) or a plain callable."""
+        sched = None
+        for cb in callbacks or []:
+            if callable(getattr(cb, "schedule", None)):
+                sched = cb.schedule
+            elif callable(cb):
+                sched = cb
+        hist = self._trainer(batch_size).fit(x, y, batch_size, epochs, shuffle, sched, verbose=int(bool(verbose)))
+        self._dirty = True
+        if validation_data is not None:
+            vx, vy = validation_data
+            p = self.predict(vx)
+            hist["val_accuracy"] = [float(np.mean(np.argmax(p, axis=1) == np.argmax(np.asarray(vy), axis=-1)
+                                                  if np.asarray(vy).ndim == 2 else np.argmax(p, axis=1) == np.asarray(vy)))]
+        return hist
+
     def get_weights(self) -> List[np.ndarray]:
+        if getattr(self, "_dirty", False):
+            self._pull_trained_weights()
+            self._dirty = False
         return [self._weights[n].copy() for n, _ in tensor_table(self.spec)]
 
     def set_weights(self, arrays: Sequence[np.ndarray]) -> None:

@@ -1,0 +1,189 @@
+"""Training step and its data-parallel orchestration.
+
+Mirrors what the reference does around ``model.fit`` (pred/train_PTM/trainer.py:
+304-339): ``compile(optimizer=AdamW(learning_rate, weight_decay), loss=focal_loss)``
+then per batch forward (training mode) -> class-balanced BCE (trainer.py:36-54) ->
+backward -> AdamW.  The arithmetic runs in libdptm.so (``dptm_trainer_*``); this module
+is host logic only: batching, the learning-rate schedule of trainer.py:56-59, and the
+data-parallel exchange (one process per GPU):
+
+  1. all-reduce (sum) of ``[N, N_pos]`` so every replica weights its samples with the
+     GLOBAL batch counts the single-device loss definition uses (trainer.py:39-44);
+  2. local forward/backward (BatchNorm normalises with the replica's own batch statistics);
+  3. ONE all-reduce (sum) over the flat fp32 gradient buffer: every tensor's gradient in
+     one bucket, with the batch mean/variance of every BatchNorm riding in the slots of
+     its (untrained) moving statistics;
+  4. identical AdamW update on every replica; moving statistics move towards the
+     replica-averaged batch statistics, so replicas stay bit-identical.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _native
+from .sharding import shard_range
+from .spec import DEFAULT_SPEC, ModelSpec, pack_blob, unpack_blob
+
+
+@dataclass
+class AdamW:
+    """Hyper-parameters of ``tensorflow_addons.optimizers.AdamW`` as the reference
+    constructs it (trainer.py:305-306); beta_1 0.9, beta_2 0.999, epsilon 1e-7 are fixed
+    in the kernel."""
+    learning_rate: float = 5e-4
+    weight_decay: float = 1e-4
+
+
+@dataclass
+class DropoutRates:
+    """Training-time dropout rates of the graph (model.py:94,136,159,189-202 with
+    config.py:52-53)."""
+    embed: float = 1e-4
+    conv: float = 0.3
+    tb: float = 0.1
+    dense: float = 0.3
+
+    @classmethod
+    def off(cls) -> "DropoutRates":
+        return cls(0.0, 0.0, 0.0, 0.0)
+
+
+def lr_schedule(epoch: int, lr: float, initial_lr: float = 5e-4, warmup_epochs: int = 5) -> float:
+    """trainer.py:56-59: linear warm-up over ``warmup_epochs``, then x0.95 per epoch."""
+    if epoch < warmup_epochs:
+        return initial_lr * (epoch + 1) / warmup_epochs
+    return lr * 0.95
+
+
+def labels_from_targets(y) -> np.ndarray:
+    """One-hot ``[N,2]`` targets (trainer.py:38 takes their argmax) or plain 0/1 labels."""
+    y = np.asarray(y)
+    if y.ndim == 2:
+        y = np.argmax(y, axis=-1)
+    return np.ascontiguousarray(y, dtype=np.int32)
+
+
+class NativeBackend:
+    """The HIP trainer on one GPU.  Batches are staged through torch tensors (device
+    memory + stream plumbing only)."""
+
+    def __init__(self, weights: Dict[str, np.ndarray], spec: ModelSpec = DEFAULT_SPEC, device: int = 0,
+                 max_batch: int = 64):
+        import torch
+        self.torch = torch
+        self.spec = spec
+        self.device = torch.device(f"cuda:{device}")
+        torch.cuda.set_device(self.device)
+        self.trainer = _native.Trainer(pack_blob(weights, spec), spec, device, max_batch)
+        ptr, count = self.trainer.grad_buffer()
+        self._grad_view = self._wrap(ptr, count)
+
+    def _wrap(self, ptr: int, count: int):
+        """torch view of library-owned device memory (for the RCCL all-reduce)."""
+        class _Ext:
+            __cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+        return self.torch.as_tensor(_Ext(), device=self.device)
+
+    def forward_backward(self, x: Sequence[np.ndarray], labels: np.ndarray, n_global: int, n_pos_global: int,
+                         seed: int, rates: DropoutRates, l2: float, l2_scale: float) -> float:
+        t = self.torch
+        d = [t.from_numpy(np.ascontiguousarray(a)).to(self.device) for a in x]
+        lab = t.from_numpy(np.ascontiguousarray(labels, dtype=np.int32)).to(self.device)
+        o = _native.TrainOpts()
+        o.seed = seed & 0xFFFFFFFF
+        o.rate_embed, o.rate_conv, o.rate_tb, o.rate_dense = rates.embed, rates.conv, rates.tb, rates.dense
+        o.n_global, o.n_pos_global = int(n_global), int(n_pos_global)
+        o.l2, o.l2_scale = l2, l2_scale
+        st = t.cuda.current_stream().cuda_stream
+        loss = self.trainer.forward_backward(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
+                                             d[4].data_ptr(), lab.data_ptr(), len(labels), o, True, st)
+        return loss
+
+    def allreduce_grads(self, group=None) -> None:
+        import torch.distributed as dist
+        dist.all_reduce(self._grad_view, op=dist.ReduceOp.SUM, group=group)
+
+    def apply(self, lr: float, weight_decay: float, stat_scale: float = 1.0) -> None:
+        self.trainer.apply(lr, weight_decay, 1.0, stat_scale, self.torch.cuda.current_stream().cuda_stream)
+
+    def weights(self) -> Dict[str, np.ndarray]:
+        return unpack_blob(self.trainer.get_weights(), self.spec)
+
+    def close(self) -> None:
+        self.trainer.close()
+
+
+class DataParallelTrainer:
+    """One training step over the global batch ``(x, y)``; every rank calls it with the
+    same arrays and scores its own contiguous shard (``shard_range``)."""
+
+    def __init__(self, backend, optimizer: AdamW = AdamW(), rates: DropoutRates = DropoutRates(),
+                 l2: float = 1e-4, group=None):
+        self.backend = backend
+        self.optimizer = optimizer
+        self.rates = rates
+        self.l2 = l2
+        self.group = group
+        self.steps = 0
+
+    def _dist(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist, dist.get_rank(self.group), dist.get_world_size(self.group)
+        return None, 0, 1
+
+    def train_on_batch(self, x: Sequence[np.ndarray], y, lr: Optional[float] = None, seed: Optional[int] = None) -> float:
+        import torch
+        dist, rank, world = self._dist()
+        labels = labels_from_targets(y)
+        n = len(labels)
+        if any(len(a) != n for a in x) or len(x) != 5:
+            raise ValueError("train_on_batch expects [x21, x33, x51, struct, esm] and matching targets")
+        lo, hi = shard_range(n, rank, world)
+        if hi - lo < 1:
+            raise ValueError("every replica needs at least one sample of the batch")
+        local_x = [np.asarray(a)[lo:hi] for a in x]
+        local_y = labels[lo:hi]
+        counts = torch.tensor([float(hi - lo), float(local_y.sum())], dtype=torch.float64)
+        if dist is not None:
+            cdev = counts.cuda() if dist.get_backend(self.group) == "nccl" else counts
+            dist.all_reduce(cdev, op=dist.ReduceOp.SUM, group=self.group)
+            counts = cdev.cpu()
+        n_global, n_pos = int(round(counts[0].item())), int(round(counts[1].item()))
+        step_seed = (self.steps if seed is None else seed) * 1000003 + rank
+        loss = self.backend.forward_backward(local_x, local_y, n_global, n_pos, step_seed, self.rates, self.l2, 1.0 / world)
+        if dist is not None:
+            self.backend.allreduce_grads(self.group)
+            lt = torch.tensor([loss], dtype=torch.float64)
+            ldev = lt.cuda() if dist.get_backend(self.group) == "nccl" else lt
+            dist.all_reduce(ldev, op=dist.ReduceOp.SUM, group=self.group)
+            loss = float(ldev.cpu().item())
+        self.backend.apply(self.optimizer.learning_rate if lr is None else lr, self.optimizer.weight_decay, 1.0 / world)
+        self.steps += 1
+        return loss
+
+    def fit(self, x: Sequence[np.ndarray], y, batch_size: int = 64, epochs: int = 1, shuffle: bool = True,
+            lr_scheduler: Optional[Callable[[int, float], float]] = None, seed: int = 0, verbose: int = 0) -> Dict[str, List[float]]:
+        """``model.fit`` loop (trainer.py:332-339) without the reference's callbacks other
+        than the learning-rate schedule."""
+        labels = labels_from_targets(y)
+        n = len(labels)
+        lr = self.optimizer.learning_rate
+        hist: Dict[str, List[float]] = {"loss": [], "lr": []}
+        rng = np.random.default_rng(seed)
+        for ep in range(epochs):
+            if lr_scheduler is not None:
+                lr = float(lr_scheduler(ep, lr))
+            order = rng.permutation(n) if shuffle else np.arange(n)
+            losses = []
+            for s in range(0, n, batch_size):
+                idx = order[s:s + batch_size]
+                losses.append(self.train_on_batch([np.asarray(a)[idx] for a in x], labels[idx], lr))
+            hist["loss"].append(float(np.mean(losses)))
+            hist["lr"].append(lr)
+            if verbose:
+                print(f"epoch {ep + 1}/{epochs} - loss {hist['loss'][-1]:.4f} - lr {lr:.2e}")
+        return hist

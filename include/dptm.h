@@ -182,15 +182,19 @@ int dptm_trainer_forward_backward(dptm_trainer* t, const uint8_t* tok21, const u
                                   float* loss_out, void* stream);
 
 /* Device address and length (floats) of the flat gradient buffer: one contiguous fp32
- * array holding every tensor's gradient (256-byte aligned slots, padding stays zero), the
- * single bucket a data-parallel job all-reduces per step. */
+ * array holding every tensor's gradient (256-byte aligned slots, padding stays zero; the
+ * slots of the BatchNorm moving statistics hold the batch statistics), the single bucket
+ * a data-parallel job all-reduces per step. */
 int dptm_trainer_grad_buffer(dptm_trainer* t, float** dev_ptr, int64_t* count);
 int64_t dptm_trainer_param_floats(const dptm_trainer* t);
 
 /* tensorflow-addons AdamW (trainer.py:305-306): var -= weight_decay*var, then Adam with
- * beta1 0.9, beta2 0.999, eps 1e-7 on grad_scale * gradient; BatchNorm moving statistics
- * take the values computed by the last forward (momentum 0.99). */
-int dptm_trainer_apply(dptm_trainer* t, float lr, float weight_decay, float grad_scale, void* stream);
+ * beta1 0.9, beta2 0.999, eps 1e-7 on grad_scale * gradient.  The BatchNorm moving
+ * statistics are not trained: their slots of the gradient buffer carry the batch mean /
+ * variance of the last forward (so the one all-reduce also sums them over replicas) and
+ * they move as stat = 0.99*stat + 0.01 * stat_scale * slot (stat_scale = 1/replicas). */
+int dptm_trainer_apply(dptm_trainer* t, float lr, float weight_decay, float grad_scale,
+                       float stat_scale, void* stream);
 
 /* Host copies in the canonical blob order (dptm_weight_count floats); they wait for the GPU. */
 int dptm_trainer_get_weights(dptm_trainer* t, float* host_out);

@@ -158,7 +158,7 @@ class TrainRef:
         x = self._bn(F.silu(x @ p["t2.k"] + p["t2.b"]), "t2.bn", (0,))
         return torch.softmax(x @ p["head.k"] + p["head.b"], dim=-1)
 
-    def loss(self, proba, labels, n_global=None, n_pos_global=None, with_l2=True):
+    def loss(self, proba, labels, n_global=None, n_pos_global=None, with_l2=True, l2_scale=1.0):
         """trainer.py:36-54 (+ the kernel regularisers Keras adds to the compiled loss)."""
         y = torch.as_tensor(np.asarray(labels).astype(np.int64))
         onehot = F.one_hot(y, 2).to(self.dtype)
@@ -170,20 +170,24 @@ class TrainRef:
         o = proba.clamp(K_EPS, 1.0 - K_EPS)
         bce = -(onehot * torch.log(o + K_EPS) + (1 - onehot) * torch.log(1 - o + K_EPS))
         data = (wts.unsqueeze(1) * bce).sum() / (n * 2.0)
-        reg = sum((self.p[k] ** 2).sum() for k in L2_TENSORS) * L2 if with_l2 else 0.0
+        reg = sum((self.p[k] ** 2).sum() for k in L2_TENSORS) * (L2 * l2_scale) if with_l2 else 0.0
         return data + reg
+
+    def grads(self, inputs, labels, seed=0, rates=None, n_global=None, n_pos_global=None, l2_scale=1.0):
+        """Forward + backward only.  Returns (loss share, grads dict of numpy arrays)."""
+        for k in self.trainable:
+            self.p[k].grad = None
+        proba = self.forward(inputs, seed, rates)
+        loss = self.loss(proba, labels, n_global, n_pos_global, True, l2_scale)
+        loss.backward()
+        return float(loss.detach()), {k: self.p[k].grad.detach().clone().numpy() for k in self.trainable}
 
     def step(self, inputs, labels, lr=5e-4, weight_decay=1e-4, seed=0, rates=None,
              n_global=None, n_pos_global=None):
         """One training step.  Returns (loss, grads dict).  Updates weights and BN stats."""
-        for k in self.trainable:
-            self.p[k].grad = None
-        proba = self.forward(inputs, seed, rates)
-        loss = self.loss(proba, labels, n_global, n_pos_global)
-        loss.backward()
-        grads = {k: self.p[k].grad.detach().clone() for k in self.trainable}
+        loss, grads = self.grads(inputs, labels, seed, rates, n_global, n_pos_global)
         self.apply(grads, lr, weight_decay)
-        return float(loss.detach()), {k: g.numpy() for k, g in grads.items()}
+        return loss, grads
 
     def apply(self, grads, lr=5e-4, weight_decay=1e-4, b1=0.9, b2=0.999, eps=1e-7):
         self.t += 1

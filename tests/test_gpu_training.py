@@ -90,3 +90,22 @@ def test_two_steps_track_reference():
     for k, v in ref.weights().items():
         assert np.abs(got[k] - v).max() < 1e-4 * max(1.0, np.abs(v).max()), k
     tr.close()
+
+
+def test_keras_like_fit_reduces_loss_and_updates_predictions():
+    """compile / fit / predict round trip through the Model surface (trainer.py:304-339)."""
+    from deepptmpred_amd.model import create_ptm_model
+    from deepptmpred_amd.training import AdamW, lr_schedule
+    m = create_ptm_model(seed=5)
+    x = spec.synthetic_inputs(256, 77)
+    y = (x[3][:, 0] > 125).astype(np.int64)           # a learnable rule: SASA above the median
+    before = m.predict(x)
+    m.compile(optimizer=AdamW(learning_rate=5e-4, weight_decay=1e-4), loss=None, metrics=["accuracy"])
+    hist = m.fit(x, np.eye(2)[y], batch_size=64, epochs=6, verbose=0,
+                 callbacks=[lambda ep, lr: lr_schedule(ep, lr)])
+    assert len(hist["loss"]) == 6 and hist["loss"][-1] < hist["loss"][0]
+    after = m.predict(x)
+    assert np.isfinite(after).all() and np.abs(after - before).max() > 1e-3
+    ws = m.get_weights()
+    assert all(np.isfinite(w).all() for w in ws)
+    m.close()
