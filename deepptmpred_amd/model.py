@@ -200,7 +200,19 @@ class Model:
         return dict(self._weights)
 
     def save(self, filepath: str) -> None:
-        save_flat(filepath, self._weights, self.spec)
+        """``model.save(path)``: a Keras-2 HDF5 weight tree for ``*.h5`` / ``*.hdf5`` paths
+        (trainer.py:321-326 checkpoints), the flat ``.dptm`` container otherwise."""
+        if getattr(self, "_dirty", False):
+            self._pull_trained_weights()
+            self._dirty = False
+        path = os.fspath(filepath)
+        if path.endswith((".h5", ".hdf5", ".keras.h5")):
+            from .keras_h5 import write_keras_h5
+            write_keras_h5(path, self._weights, self.spec)
+        else:
+            save_flat(path, self._weights, self.spec)
+
+    save_weights = save
 
     def count_params(self) -> int:
         return int(self._blob.size)

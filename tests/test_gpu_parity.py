@@ -169,3 +169,26 @@ def test_bad_position_is_rejected(model):
         model.predict_protein("ACDEFGHIK", [0], np.zeros((1, 8)))
     with pytest.raises(IndexError):
         model.predict_protein("ACDEFGHIK", [10], np.zeros((1, 8)))
+
+
+def test_predictor_table_on_gpu(model, weights, golden_dir, tmp_path):
+    """The predict.py stand-in end to end: fused (device assembly) and unfused paths give the
+    same table, and the probabilities equal the oracle's."""
+    from deepptmpred_amd.predictor import PredictConfig, PTMPredictor
+    g = np.load(os.path.join(golden_dir, "proteins.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "proteins.json")))["P10636"]
+    seq, pos, esm = meta["sequence"], g["P10636_phospho_positions"], g["P10636_phospho_esm"]
+    cfg = PredictConfig("phosphorylation", str(tmp_path))
+    os.makedirs(cfg.custom_esm_dir)
+    table = np.zeros((meta["esm_rows"], 1280))
+    table[pos - 1] = esm
+    np.savez(os.path.join(cfg.custom_esm_dir, "P10636_full_esm.npz"), features=table)
+    pred = PTMPredictor(cfg, model=model)
+    a = pred.predict_ptm_sites("P10636", seq)                # case.py: all 80 S/T sites
+    b = pred.predict_ptm_sites("P10636", seq, fused=False)
+    assert len(a) == 80 and a["position"].tolist() == pos.tolist()
+    assert np.array_equal(a["probability"].to_numpy(), b["probability"].to_numpy())
+    toks = [g[f"P10636_phospho_tok{w}"] for w in (21, 33, 51)]
+    ref = oracle(weights, toks + [np.tile(O.DEFAULT_STRUCT_ROW, (80, 1)), esm])[:, 1]
+    assert np.abs(a["probability"].to_numpy() - ref).max() < TOL
+    assert set(a[a["position"].isin([202, 205, 231, 262, 356])]["residue"]) <= {"S", "T"}   # case.py:541

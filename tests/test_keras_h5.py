@@ -1,0 +1,140 @@
+"""Keras-2 HDF5 checkpoints without h5py: the pure-Python HDF5 subset reader/writer
+against the real libhdf5 (driven through ctypes when the image has one), and the Keras
+layer/weight layout mapping."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import h5_ctypes  # noqa: E402
+
+from deepptmpred_amd import spec  # noqa: E402
+from deepptmpred_amd.hdf5_min import H5File, H5FormatError, H5Writer  # noqa: E402
+from deepptmpred_amd.keras_h5 import keras_layer_table, read_keras_h5, write_keras_h5  # noqa: E402
+from deepptmpred_amd.model import Model, load_model  # noqa: E402
+
+LIB = h5_ctypes.load()
+needs_lib = pytest.mark.skipif(LIB is None, reason="no libhdf5 on this machine")
+
+
+def _tree(n_groups=70):
+    rng = np.random.default_rng(0)
+    ds = {f"/model_weights/layer_{i}/layer_{i}/kernel:0": rng.normal(size=(3 + i % 5, 5)).astype(np.float32)
+          for i in range(n_groups)}
+    ds["/model_weights/deep/a/b/c/bias:0"] = rng.normal(size=(7,)).astype(np.float32)
+    attrs = {("/model_weights", "layer_names"): [f"layer_{i}".encode() for i in range(n_groups)] + [b"deep"]}
+    for i in range(n_groups):
+        attrs[(f"/model_weights/layer_{i}", "weight_names")] = [f"layer_{i}/kernel:0".encode()]
+    return ds, attrs
+
+
+def test_writer_reader_roundtrip(tmp_path):
+    ds, attrs = _tree()
+    w = H5Writer()
+    for k, v in ds.items():
+        w.create_dataset(k, v)
+    for (o, n), v in attrs.items():
+        w.set_attr(o, n, v)
+    w.set_attr("/", "keras_version", "2.15.0")
+    w.set_attr("/", "answer", np.array([1.5, 2.5], dtype=np.float32))
+    p = str(tmp_path / "a.h5")
+    w.save(p)
+    f = H5File(p)
+    assert f.attrs["keras_version"] == b"2.15.0" and f.attrs["answer"].tolist() == [1.5, 2.5]
+    assert len(f["model_weights"].keys()) == 71
+    for k, v in ds.items():
+        assert np.array_equal(f[k].read(), v)
+    assert [bytes(x) for x in f["model_weights"].attrs["layer_names"]][:2] == [b"layer_0", b"layer_1"]
+    with pytest.raises(KeyError):
+        f["model_weights/nope"]
+    bad = tmp_path / "bad.h5"
+    bad.write_bytes(b"not hdf5 at all")
+    with pytest.raises(H5FormatError):
+        H5File(str(bad))
+
+
+@needs_lib
+def test_reader_reads_what_libhdf5_writes(tmp_path):
+    ds, attrs = _tree()
+    p = str(tmp_path / "ref.h5")
+    h5_ctypes.write_tree(LIB, p, ds, attrs)
+    f = H5File(p)
+    for k, v in ds.items():
+        assert np.array_equal(f[k].read(), v)
+    assert [bytes(x).rstrip(b"\x00") for x in f["model_weights"].attrs["layer_names"]] == attrs[("/model_weights", "layer_names")]
+
+
+@needs_lib
+def test_libhdf5_reads_what_writer_writes(tmp_path):
+    ds, attrs = _tree()
+    w = H5Writer()
+    for k, v in ds.items():
+        w.create_dataset(k, v)
+    for (o, n), v in attrs.items():
+        w.set_attr(o, n, v)
+    p = str(tmp_path / "mine.h5")
+    w.save(p)
+    for k, v in ds.items():
+        assert np.array_equal(h5_ctypes.read_dataset(LIB, p, k), v)
+    got = [x.rstrip(b"\x00") for x in h5_ctypes.read_str_attr(LIB, p, "/model_weights", "layer_names")]
+    assert got == attrs[("/model_weights", "layer_names")]
+
+
+def test_keras_layer_table_covers_every_tensor():
+    table = keras_layer_table()
+    canon = [c for _, pairs in table for _, c in pairs]
+    assert sorted(canon) == sorted(n for n, _ in spec.tensor_table())
+    names = [ln for ln, _ in table]
+    assert len(names) == len(set(names)) == 40
+    # Dense numbering counts the Dense layers inside the transformer blocks
+    assert {"dense_12", "dense_25", "dense_38", "dense_39", "dense_44", "conv1d_8", "batch_normalization_9",
+            "transformer_block_5", "embedding_2", "position_embedding"} <= set(names)
+    tb = dict(table)["transformer_block"]
+    assert [c.split(".")[-1] for _, c in tb] == ["wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "ffn1_k", "ffn1_b",
+                                                  "ffn2_k", "ffn2_b", "ln1_g", "ln1_b", "ln2_g", "ln2_b"]
+
+
+def test_keras_checkpoint_roundtrip_through_model(tmp_path):
+    w = spec.synthetic_weights(11)
+    p = str(tmp_path / "ptm_data_210_39_64_best_model.h5")
+    Model(w).save(p)
+    back = read_keras_h5(p)
+    assert all(np.array_equal(back[k], w[k]) for k in w)
+    m = load_model(p, custom_objects={"PositionEmbedding": None, "focal_loss": None})
+    for a, (name, _) in zip(m.get_weights(), spec.tensor_table()):
+        assert np.array_equal(a, w[name])
+    # a save_weights-style file: the same tree at the root
+    f = H5File(p)
+    assert f.attrs["backend"] == b"tensorflow"
+    assert len(f["model_weights"].attrs["layer_names"]) == 40
+
+
+@needs_lib
+def test_read_checkpoint_written_by_libhdf5(tmp_path):
+    """The same Keras layout produced by the real library (as h5py would), read by us."""
+    w = spec.synthetic_weights(12)
+    table = keras_layer_table()
+    ds, attrs = {}, {("/model_weights", "layer_names"): [ln.encode() for ln, _ in table]}
+    for ln, pairs in table:
+        attrs[(f"/model_weights/{ln}", "weight_names")] = [kn.encode() for kn, _ in pairs]
+        for kn, canon in pairs:
+            ds[f"/model_weights/{ln}/{kn}"] = w[canon]
+    p = str(tmp_path / "keras_like.h5")
+    h5_ctypes.write_tree(LIB, p, ds, attrs)
+    back = read_keras_h5(p)
+    assert all(np.array_equal(back[k], w[k]) for k in w)
+    # and the real library can read ours
+    p2 = str(tmp_path / "ours.h5")
+    write_keras_h5(p2, w)
+    assert np.array_equal(h5_ctypes.read_dataset(LIB, p2, "/model_weights/dense_40/dense_40/kernel:0"), w["esm1.k"])
+
+
+def test_wrong_layout_is_reported(tmp_path):
+    w = H5Writer()
+    w.create_dataset("/model_weights/something/kernel:0", np.zeros((2, 2), np.float32))
+    p = str(tmp_path / "other.h5")
+    w.save(p)
+    with pytest.raises(H5FormatError):
+        read_keras_h5(p)
