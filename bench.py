@@ -170,6 +170,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sites", type=int, default=1_000_000, help="sites per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3", "f16", "bf16"],
+                    help="arithmetic of the sequence-branch matrix products for the headline number")
     ap.add_argument("--train", action="store_true",
                     help="measure the training step (BASELINE config 5) instead of scoring")
     ap.add_argument("--batch", type=int, default=64, help="--train: sites per GPU per step")
@@ -198,6 +200,7 @@ def main() -> None:
     weights = spec.synthetic_weights(7)
     model = Model(weights, device=local)
     sc = model.scorer
+    sc.set_precision(args.precision)
     n = args.sites
     x = device_inputs(n, 1234 + rank, dev)
     out = torch.empty((n, 2), device=dev, dtype=torch.float32)
@@ -247,7 +250,7 @@ def main() -> None:
         line = {
             "metric": "windows scored/sec", "value": value, "unit": "sites/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic (device-generated sites, seeded synthetic weights)",
             "config": {"workload": "config 3: 1M synthetic sites (windows 21/33/51 + ESM-2 1280 + 8 struct), fp32, 1 MI355X",
                        "sites_per_gpu": n, "parallelism": f"dp{world} (sites sharded, no collective)"},

@@ -21,11 +21,13 @@ DPTM_OK, DPTM_EINVAL, DPTM_EHIP, DPTM_ENOMEM = 0, -1, -2, -3
 PROF_NAMES = ("assemble", "branch21", "branch33", "branch51", "struct", "esm1", "esm2",
               "trunk1", "trunk2", "head")
 
+PRECISIONS = {"f32": 0, "bf16": 1, "f16": 2, "f16x3": 3}
+
 EXPORTS = (
     "dptm_weight_count", "dptm_create", "dptm_destroy", "dptm_score", "dptm_score_protein",
     "dptm_score_device", "dptm_score_protein_device", "dptm_assemble_device", "dptm_sync",
     "dptm_profile_begin", "dptm_profile_end", "dptm_chunk_sites", "dptm_last_error",
-    "dptm_trainer_create", "dptm_trainer_destroy", "dptm_trainer_forward_backward",
+    "dptm_set_precision", "dptm_trainer_create", "dptm_trainer_destroy", "dptm_trainer_forward_backward",
     "dptm_trainer_grad_buffer", "dptm_trainer_param_floats", "dptm_trainer_apply",
     "dptm_trainer_get_weights", "dptm_trainer_get_grads", "dptm_trainer_get_proba",
     "dptm_trainer_last_error",
@@ -120,6 +122,8 @@ def load_library() -> C.CDLL:
     lib.dptm_profile_begin.argtypes = [vp]
     lib.dptm_profile_end.restype = C.c_int
     lib.dptm_profile_end.argtypes = [vp, C.c_void_p, C.c_void_p]
+    lib.dptm_set_precision.restype = C.c_int
+    lib.dptm_set_precision.argtypes = [vp, C.c_int]
     lib.dptm_chunk_sites.restype = C.c_int64
     lib.dptm_chunk_sites.argtypes = [vp]
     lib.dptm_last_error.restype = C.c_char_p
@@ -230,6 +234,12 @@ class Scorer:
 
     def sync(self) -> None:
         _check(self._lib, self._lib.dptm_sync(self._h), "dptm_sync")
+
+    def set_precision(self, mode) -> None:
+        """mode: 'f32' | 'bf16' | 'f16' | 'f16x3' (or the DPTM_PREC_* integer)."""
+        if isinstance(mode, str):
+            mode = PRECISIONS[mode.lower()]
+        _check(self._lib, self._lib.dptm_set_precision(self._h, int(mode)), "dptm_set_precision")
 
     def profile_begin(self) -> None:
         _check(self._lib, self._lib.dptm_profile_begin(self._h), "dptm_profile_begin")

@@ -51,6 +51,45 @@ void pack_matrix(const float* W, int K, int N, int n_pad, float* dst) {
             }
 }
 
+inline uint16_t f32_to_bf16(float f) {   // round to nearest even; NaN stays NaN
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) return (uint16_t)((u >> 16) | 0x0040u);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+inline uint16_t f32_to_f16_bits(float f) {
+    _Float16 h = (_Float16)f;
+    uint16_t b;
+    std::memcpy(&b, &h, 2);
+    return b;
+}
+inline float f16_bits_to_f32(uint16_t b) {
+    _Float16 h;
+    std::memcpy(&h, &b, 2);
+    return (float)h;
+}
+
+// Half-precision image of a Keras kernel W [K][N] for v_mfma_f32_32x32x16: 16-byte unit
+// ((t*(K/16) + ks)*64 + lane) holds, for idx = 0..7, W[8*(2ks + (idx>>2)) + 4h + (idx&3)][32t + j].
+// kind 0: bfloat16;  1: float16 (hi);  2: float16 of the remainder W - hi (lo).
+void pack_matrix_half(const float* W, int K, int N, int kind, uint16_t* dst) {
+    const int KS = K / 16;
+    for (int t = 0; t < N / 32; ++t)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int h = lane >> 5, j = lane & 31;
+                for (int idx = 0; idx < 8; ++idx) {
+                    const int kk = 8 * (2 * ks + (idx >> 2)) + 4 * h + (idx & 3);
+                    const float w = W[(size_t)kk * N + 32 * t + j];
+                    uint16_t v;
+                    if (kind == 0) v = f32_to_bf16(w);
+                    else if (kind == 1) v = f32_to_f16_bits(w);
+                    else v = f32_to_f16_bits(w - f16_bits_to_f32(f32_to_f16_bits(w)));
+                    dst[((((size_t)t * KS + ks) * 64 + lane) * 8) + idx] = v;
+                }
+            }
+}
+
 // v has F features; dst gets f_pad/4 floats grouped [half][group][4].
 void pack_vector(const float* v, int F, int f_pad, float* dst) {
     const int g8 = f_pad / 8;
@@ -102,6 +141,8 @@ struct dptm_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     float* d_branch[3] = {nullptr, nullptr, nullptr};
+    uint16_t* d_branch_half[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // [branch][bf16 | f16 hi | f16 lo]
+    int precision = kModeF32;
     DenseLayer strct, esm1, esm2, t1, t2, head;
     // per-chunk workspace
     float* d_concat = nullptr;
@@ -161,10 +202,17 @@ int upload(const std::vector<float>& v, float** d) {
 
 // Packs one sequence branch (tensor order of spec.py:tensor_table) into the buffer
 // layout of dptm_layout.h.
-void pack_branch(Reader& rd, int W, std::vector<float>& buf) {
+void pack_branch(Reader& rd, int W, std::vector<float>& buf, std::vector<uint16_t> (&half)[3]) {
     buf.assign((size_t)kBranchF4 * 4, 0.0f);
+    for (auto& hbuf : half) hbuf.assign((size_t)kBranchF4 * 4, 0);   // same offsets, in 16-bit units: float4 offset/2 = uint4 offset
     float* B = buf.data();
     auto f4 = [&](int off) { return B + (size_t)off * 4; };
+    // a matrix at float4 offset `off` has its half images at uint4 offset off/2 = 16-bit offset off*4
+    auto pack_matrix = [&](const float* Wm, int K, int N, int n_pad, float* dst) {
+        ::pack_matrix(Wm, K, N, n_pad, dst);
+        const size_t off16 = (size_t)(dst - B);   // floats from the start == 16-bit units of the half image
+        for (int kind = 0; kind < 3; ++kind) pack_matrix_half(Wm, K, N, kind, half[kind].data() + off16);
+    };
     std::memcpy(f4(kOffEmb), rd.take(kCodes * kD), sizeof(float) * kCodes * kD);
     std::memcpy(f4(kOffPos), rd.take((size_t)W * kD), sizeof(float) * W * kD);
     pack_matrix(rd.take(kD * kD), kD, kD, kD, f4(kOffScW));
@@ -292,7 +340,13 @@ int score_chunk(dptm_handle* h, const uint8_t* const tok[3], const float* strct,
                 int64_t esm_ld, const int32_t* esm_row, int64_t m, float* out, hipStream_t st) {
     for (int b = 0; b < 3; ++b) {
         Prof p(h, st, DPTM_PROF_BRANCH21 + b);
-        HIP_TRY(launch_branch(kWin[b], h->d_branch[b], tok[b], m, h->d_concat, kConcat, b * kD, st));
+        if (h->precision == kModeF32) {
+            HIP_TRY(launch_branch(kWin[b], h->d_branch[b], tok[b], m, h->d_concat, kConcat, b * kD, st));
+        } else {
+            const uint16_t* hi = h->d_branch_half[b][h->precision == kModeBF16 ? 0 : 1];
+            HIP_TRY(launch_branch_h(h->precision, kWin[b], h->d_branch[b], hi, h->d_branch_half[b][2], tok[b], m,
+                                    h->d_concat, kConcat, b * kD, st));
+        }
     }
     int rc;
     if ((rc = run_dense(h, h->strct, kEpiSwishAffine, strct, kStruct, nullptr, m, h->d_concat, kConcat,
@@ -344,6 +398,8 @@ void dptm_destroy(dptm_handle* h) {
     }
     for (int b = 0; b < 3; ++b) {
         if (h->d_branch[b]) (void)hipFree(h->d_branch[b]);
+        for (int kind = 0; kind < 3; ++kind)
+            if (h->d_branch_half[b][kind]) (void)hipFree(h->d_branch_half[b][kind]);
         if (h->d_tok[b]) (void)hipFree(h->d_tok[b]);
         if (h->s_tok[b]) (void)hipFree(h->s_tok[b]);
     }
@@ -400,9 +456,17 @@ int dptm_create(const void* weights, size_t nbytes, const dptm_spec* spec, int d
 
     Reader rd{static_cast<const float*>(weights)};
     std::vector<float> buf;
+    std::vector<uint16_t> half[3];
     for (int b = 0; b < 3; ++b) {
-        pack_branch(rd, kWin[b], buf);
+        pack_branch(rd, kWin[b], buf, half);
         if ((rc = upload(buf, &h->d_branch[b]))) return bail(rc);
+        for (int kind = 0; kind < 3; ++kind) {
+            const size_t bytes = half[kind].size() * sizeof(uint16_t);
+            if (hipMalloc(reinterpret_cast<void**>(&h->d_branch_half[b][kind]), bytes) != hipSuccess)
+                return bail(fail(DPTM_ENOMEM, "dptm_create: device allocation failed"));
+            if (hipMemcpy(h->d_branch_half[b][kind], half[kind].data(), bytes, hipMemcpyHostToDevice) != hipSuccess)
+                return bail(fail(DPTM_EHIP, "dptm_create: upload failed"));
+        }
     }
     if ((rc = make_dense(rd, kStruct, kStructUnits, kStructUnits, true, h->strct))) return bail(rc);
     if ((rc = make_dense(rd, kEsm, kEsm1, kEsm1, true, h->esm1))) return bail(rc);
@@ -432,6 +496,14 @@ int dptm_create(const void* weights, size_t nbytes, const dptm_spec* spec, int d
 }
 
 int64_t dptm_chunk_sites(const dptm_handle* h) { return h ? kChunkSites : 0; }
+
+int dptm_set_precision(dptm_handle* h, int mode) {
+    if (!h) return fail(DPTM_EINVAL, "dptm_set_precision: NULL handle");
+    if (mode != kModeF32 && mode != kModeBF16 && mode != kModeF16 && mode != kModeF16X3)
+        return fail(DPTM_EINVAL, "dptm_set_precision: unknown mode");
+    h->precision = mode;
+    return DPTM_OK;
+}
 
 int dptm_sync(dptm_handle* h) {
     if (!h) return fail(DPTM_EINVAL, "dptm_sync: NULL handle");

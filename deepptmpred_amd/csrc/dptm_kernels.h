@@ -10,6 +10,9 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 enum DenseEpilogue { kEpiSwish = 0, kEpiSwishAffine = 1, kEpiHead = 2 };
 
+// arithmetic of the matrix products in the fused sequence branch (DPTM_PREC_* in dptm.h)
+enum PrecisionMode { kModeF32 = 0, kModeBF16 = 1, kModeF16 = 2, kModeF16X3 = 3 };
+
 struct DenseArgs {
     const float* x;            // [rows][ldx] fp32 activations
     int64_t ldx;               // floats per row of x
@@ -28,6 +31,9 @@ struct DenseArgs {
 
 hipError_t launch_branch(int w, const float* params, const uint8_t* tok, int64_t n, float* out,
                          int ldo, int col_off, hipStream_t st);
+// half-precision-MFMA branch (dptm_kernels_h.hip): whi/wlo = packed half weight images of the branch
+hipError_t launch_branch_h(int mode, int w, const float* params, const void* whi, const void* wlo, const uint8_t* tok,
+                           int64_t n, float* out, int ldo, int col_off, hipStream_t st);
 hipError_t launch_dense(const DenseArgs& a, int epi, hipStream_t st);
 hipError_t launch_assemble(const uint8_t* codes, int64_t L, int64_t esm_rows,
                            const int32_t* positions, int64_t n, uint8_t* t21, uint8_t* t33,

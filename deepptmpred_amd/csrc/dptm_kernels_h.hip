@@ -1,0 +1,557 @@
+// Half-precision-MFMA variant of the fused sequence branch (gfx950).
+//
+// Same graph and the same fp32 "chain layout" of activations as branch_kernel in
+// dptm_kernels.hip, but every contraction -- dense layers, conv taps AND the attention
+// products -- runs on v_mfma_f32_32x32x16_{f16,bf16} with fp32 accumulation:
+//   MODE_BF16   operands rounded to bfloat16, one MFMA per product
+//   MODE_F16    operands rounded to float16, one MFMA per product
+//   MODE_F16X3  each operand split x = hi + lo (two float16 values, |lo| <= ulp(hi)/2),
+//               products hi*hi + hi*lo + lo*hi: 3 MFMAs, ~2^-22 relative error, i.e.
+//               fp32-class results at 3/16 of the fp32 MFMA cost.  gfx950 keeps fp16
+//               subnormals in MFMA operands, so small lo parts are not flushed.
+// Attention on MFMA: S^T = K Q^T per (aligned 32-key tile, head) is ONE k=16 MFMA; keys
+// outside the query's own site are masked before the softmax; O^T = V^T P^T takes the
+// softmax tile straight from the accumulator registers as the next B operand.
+#include <hip/hip_runtime.h>
+
+#include "dptm_kernels.h"
+#include "dptm_layout.h"
+
+namespace dptm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+
+template <int MODE> struct HP;
+template <> struct HP<kModeBF16> { typedef b8 frag; typedef __bf16 elem; static constexpr bool kSplit = false; };
+template <> struct HP<kModeF16> { typedef h8 frag; typedef _Float16 elem; static constexpr bool kSplit = false; };
+template <> struct HP<kModeF16X3> { typedef h8 frag; typedef _Float16 elem; static constexpr bool kSplit = true; };
+
+__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma16(b8 a, b8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+template <int MODE>
+struct Frag {                    // one MFMA operand: 8 k-elements per lane (hi, and lo in the split mode)
+    typename HP<MODE>::frag hi, lo;
+};
+
+// 8 fp32 values (two chain-layout groups) -> operand fragment
+template <int MODE>
+__device__ __forceinline__ Frag<MODE> make_frag(const f32x4& x0, const f32x4& x1) {
+    typedef typename HP<MODE>::elem E;
+    Frag<MODE> f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f.hi[e] = (E)x0[e];
+        f.hi[4 + e] = (E)x1[e];
+    }
+    if (HP<MODE>::kSplit) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f.lo[e] = (E)(x0[e] - (float)f.hi[e]);
+            f.lo[4 + e] = (E)(x1[e] - (float)f.hi[4 + e]);
+        }
+    }
+    return f;
+}
+
+template <int MODE>
+__device__ __forceinline__ void mac(f32x16& acc, const Frag<MODE>& a, const Frag<MODE>& b) {
+    acc = mfma16(a.hi, b.hi, acc);
+    if (HP<MODE>::kSplit) {
+        acc = mfma16(a.hi, b.lo, acc);
+        acc = mfma16(a.lo, b.hi, acc);
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ typename HP<MODE>::frag as_frag(const uint4& v) {
+    return __builtin_bit_cast(typename HP<MODE>::frag, v);
+}
+template <int MODE>
+__device__ __forceinline__ uint4 as_u4(const typename HP<MODE>::frag& f) { return __builtin_bit_cast(uint4, f); }
+
+// weight fragment (t, ks) of a packed half matrix with KS k-steps per out tile
+template <int MODE>
+__device__ __forceinline__ Frag<MODE> load_w(const uint4* __restrict__ hi, const uint4* __restrict__ lo, int idx) {
+    Frag<MODE> f;
+    f.hi = as_frag<MODE>(hi[idx]);
+    if (HP<MODE>::kSplit) f.lo = as_frag<MODE>(lo[idx]);
+    return f;
+}
+
+__device__ __forceinline__ float fast_rcp_h(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float swish_h(float x) { return x * fast_rcp_h(1.0f + __expf(-x)); }
+__device__ __forceinline__ float xhalf_sum_h(float v) { return v + __shfl_xor(v, 32); }
+__device__ __forceinline__ float xhalf_max_h(float v) { return fmaxf(v, __shfl_xor(v, 32)); }
+
+template <int NT>
+__device__ __forceinline__ void acc_bias(f32x16 (&acc)[NT], const f32x4* __restrict__ vec, int h, int groups_per_half) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = vec[h * groups_per_half + 4 * t + g];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][4 * g + e] = b[e];
+        }
+}
+
+template <int NT>
+__device__ __forceinline__ void acc_x(const f32x16 (&acc)[NT], f32x4 (&x)[4 * NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[4 * t + g][e] = acc[t][4 * g + e];
+}
+
+// acc[t] += W(t)^T X^T, X given as KS operand fragments; all weight fragments of the layer are
+// fetched up front (a 64-wide layer is only KS = 4 steps deep, shorter than one L2 round trip)
+template <int MODE, int KS, int NT>
+__device__ __forceinline__ void gemm_h(f32x16 (&acc)[NT], const uint4* __restrict__ whi, const uint4* __restrict__ wlo,
+                                       const Frag<MODE> (&x)[KS], int lane) {
+    Frag<MODE> a[KS][NT];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[ks][t] = load_w<MODE>(whi, wlo, (t * KS + ks) * 64 + lane);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) mac<MODE>(acc[t], a[ks][t], x[ks]);
+}
+
+__device__ __forceinline__ void layernorm64_h(f32x4 (&x)[8], const f32x4* __restrict__ g, const f32x4* __restrict__ b, int h) {
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (x[u][0] + x[u][1]) + (x[u][2] + x[u][3]);
+    const float mean = xhalf_sum_h(s) * (1.0f / 64.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = x[u][e] - mean;
+            x[u][e] = d;
+            q = fmaf(d, d, q);
+        }
+    const float inv = rsqrtf(xhalf_sum_h(q) * (1.0f / 64.0f) + 1e-6f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const f32x4 gg = g[h * 8 + u], bb = b[h * 8 + u];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[u][e] = fmaf(x[u][e] * inv, gg[e], bb[e]);
+    }
+}
+
+// LDS images (byte offsets inside one 73,728-byte region; hi at 0, lo at kLoOff)
+constexpr int kRowB = 144;                    // fragment image: [row][4 steps][2 halves] x 16 B + 16 B pad
+constexpr int kLoOff = 256 * kRowB;           // 36,864
+constexpr int kVtRowB = 528;                  // V^T image: [feature][256 keys] x 2 B + 16 B pad
+constexpr int kVtLoOff = 64 * kVtRowB;        // 33,792
+constexpr int kRegionB = 2 * 256 * kRowB;     // 73,728 >= 2*64*528 and >= 256*68*4
+
+template <int MODE>
+__device__ __forceinline__ void store_frag(char* region, int row, int slot, int h, const Frag<MODE>& f) {
+    char* p = region + row * kRowB + (slot * 2 + h) * 16;
+    *reinterpret_cast<uint4*>(p) = as_u4<MODE>(f.hi);
+    if (HP<MODE>::kSplit) *reinterpret_cast<uint4*>(p + kLoOff) = as_u4<MODE>(f.lo);
+}
+template <int MODE>
+__device__ __forceinline__ Frag<MODE> load_frag(const char* region, int row, int slot, int h) {
+    const char* p = region + row * kRowB + (slot * 2 + h) * 16;
+    Frag<MODE> f;
+    f.hi = as_frag<MODE>(*reinterpret_cast<const uint4*>(p));
+    if (HP<MODE>::kSplit) f.lo = as_frag<MODE>(*reinterpret_cast<const uint4*>(p + kLoOff));
+    return f;
+}
+template <int MODE>
+__device__ __forceinline__ Frag<MODE> zero_frag() {
+    Frag<MODE> f;
+    const uint4 z = {0u, 0u, 0u, 0u};
+    f.hi = as_frag<MODE>(z);
+    f.lo = as_frag<MODE>(z);
+    return f;
+}
+
+template <int W, int MODE>
+__global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__ P, const uint4* __restrict__ Whi,
+                                                       const uint4* __restrict__ Wlo, const uint8_t* __restrict__ tok,
+                                                       int64_t n_sites, float* __restrict__ out, int ldo, int col_off) {
+    typedef typename HP<MODE>::elem E;
+    constexpr int S = kTileRows / W;
+    constexpr int MAXNB = (W == 51) ? 5 : 4;
+    extern __shared__ __attribute__((aligned(16))) char lds_h[];
+    char* regA = lds_h;                 // X0 fragments | K fragments | final activations (fp32 [256][68])
+    char* regB = lds_h + kRegionB;      // y1 fragments | V^T
+    float* score = reinterpret_cast<float*>(lds_h + 2 * kRegionB);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int64_t site0 = (int64_t)blockIdx.x * S;
+    const int sites_here = (int)min((int64_t)S, n_sites - site0);
+    const int rows_valid = sites_here * W;
+
+    const int row = wave * 32 + j;
+    const bool row_ok = row < rows_valid;
+    const int site_l = row_ok ? row / W : 0;
+    const int pos_l = row_ok ? row - site_l * W : 0;
+    const bool tap0_ok = row_ok && pos_l > 0;
+    const bool tap2_ok = row_ok && pos_l < W - 1;
+    // keys this lane's query may attend to: its own site, or only itself for a padding row
+    const int k_start = row_ok ? site_l * W : row;
+    const int k_len = row_ok ? W : 1;
+    // aligned 32-key tiles this wavefront needs (wave-uniform)
+    int b_lo, nb;
+    {
+        const int r_first = wave * 32;
+        if (r_first >= rows_valid) {
+            b_lo = wave;
+            nb = 1;
+        } else {
+            const int r_last = min(r_first + 31, rows_valid - 1);
+            const int kfirst = (r_first / W) * W;
+            const int klast = (r_last / W) * W + W - 1;
+            b_lo = kfirst >> 5;
+            nb = (min(klast, kTileRows - 1) >> 5) - b_lo + 1;
+        }
+    }
+    // per-tile validity masks (bit r <-> accumulator register r of the S^T tile), fixed for the kernel
+    unsigned kmask[MAXNB];
+#pragma unroll
+    for (int bi = 0; bi < MAXNB; ++bi) {
+        unsigned m = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int krow = 32 * (b_lo + bi) + (r & 3) + 8 * (r >> 2) + 4 * h;
+            m |= ((unsigned)(krow - k_start) < (unsigned)k_len ? 1u : 0u) << r;
+        }
+        kmask[bi] = bi < nb ? m : 0u;
+    }
+
+    // ---- embedding + position embedding, this lane's row in the chain layout (model.py:157-158)
+    f32x4 x1[8];
+    {
+        int t = row_ok ? tok[(site0 + site_l) * W + pos_l] : 0;
+        t = t > kCodes - 1 ? kCodes - 1 : t;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row_ok) v = P[kOffEmb + t * 16 + 2 * u + h] + P[kOffPos + pos_l * 16 + 2 * u + h];
+            x1[u] = v;
+        }
+    }
+    Frag<MODE> fx[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        fx[ks] = make_frag<MODE>(x1[2 * ks], x1[2 * ks + 1]);
+        store_frag<MODE>(regA, row, ks, h, fx[ks]);
+    }
+    __syncthreads();
+
+    // ---- residual conv block (model.py:129-141)
+    {
+        const f32x4* cv = P + kOffConvV;
+        f32x16 acc_s[2], acc_a[2];
+        acc_bias<2>(acc_s, cv + kVScB * kVec64, h, 8);
+        acc_bias<2>(acc_a, cv + kVC3aB * kVec64, h, 8);
+        const int rl = tap0_ok ? row - 1 : row, rr = tap2_ok ? row + 1 : row;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            Frag<MODE> bl = load_frag<MODE>(regA, rl, ks, h), br = load_frag<MODE>(regA, rr, ks, h);
+            if (!tap0_ok) bl = zero_frag<MODE>();
+            if (!tap2_ok) br = zero_frag<MODE>();
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int idx = (t * 4 + ks) * 64 + lane;
+                mac<MODE>(acc_s[t], load_w<MODE>(Whi + kOffScW / 2, Wlo + kOffScW / 2, idx), fx[ks]);
+                mac<MODE>(acc_a[t], load_w<MODE>(Whi + kOffC3aW / 2, Wlo + kOffC3aW / 2, idx), bl);
+                mac<MODE>(acc_a[t], load_w<MODE>(Whi + (kOffC3aW + kMat64) / 2, Wlo + (kOffC3aW + kMat64) / 2, idx), fx[ks]);
+                mac<MODE>(acc_a[t], load_w<MODE>(Whi + (kOffC3aW + 2 * kMat64) / 2, Wlo + (kOffC3aW + 2 * kMat64) / 2, idx), br);
+            }
+        }
+        f32x4 y[8];
+        acc_x<2>(acc_a, y);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const f32x4 sc = cv[kVBn1S * kVec64 + h * 8 + u], sh = cv[kVBn1T * kVec64 + h * 8 + u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[u][e] = fmaf(swish_h(y[u][e]), sc[e], sh[e]);
+        }
+        Frag<MODE> fy[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            fy[ks] = make_frag<MODE>(y[2 * ks], y[2 * ks + 1]);
+            store_frag<MODE>(regB, row, ks, h, fy[ks]);
+        }
+        __syncthreads();
+        f32x16 acc_b[2];
+        acc_bias<2>(acc_b, cv + kVC3bB * kVec64, h, 8);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            Frag<MODE> bl = load_frag<MODE>(regB, rl, ks, h), br = load_frag<MODE>(regB, rr, ks, h);
+            if (!tap0_ok) bl = zero_frag<MODE>();
+            if (!tap2_ok) br = zero_frag<MODE>();
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int idx = (t * 4 + ks) * 64 + lane;
+                mac<MODE>(acc_b[t], load_w<MODE>(Whi + kOffC3bW / 2, Wlo + kOffC3bW / 2, idx), bl);
+                mac<MODE>(acc_b[t], load_w<MODE>(Whi + (kOffC3bW + kMat64) / 2, Wlo + (kOffC3bW + kMat64) / 2, idx), fy[ks]);
+                mac<MODE>(acc_b[t], load_w<MODE>(Whi + (kOffC3bW + 2 * kMat64) / 2, Wlo + (kOffC3bW + 2 * kMat64) / 2, idx), br);
+            }
+        }
+        f32x4 s[8];
+        acc_x<2>(acc_b, x1);
+        acc_x<2>(acc_s, s);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const f32x4 sc = cv[kVBn2S * kVec64 + h * 8 + u], sh = cv[kVBn2T * kVec64 + h * 8 + u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x1[u][e] = fmaf(swish_h(x1[u][e]), sc[e], sh[e]) + s[u][e];
+        }
+    }
+
+    // ---- two transformer blocks (model.py:93-118, 172-173)
+#pragma unroll 1
+    for (int blk = 0; blk < 2; ++blk) {
+        const int To = kOffTb + blk * kTbSize;
+        const f32x4* tv = P + To + kTbVec;
+        const uint4* Thi = Whi + To / 2;
+        const uint4* Tlo = Wlo + To / 2;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fx[ks] = make_frag<MODE>(x1[2 * ks], x1[2 * ks + 1]);
+        __syncthreads();   // every wave is done with regA/regB (conv taps, or the previous block's K / V^T)
+        {   // K -> fragment image [row][head][half]
+            f32x16 acc[2];
+            acc_bias<2>(acc, tv + kVBk * kVec64, h, 8);
+            gemm_h<MODE, 4, 2>(acc, Thi + kTbWk / 2, Tlo + kTbWk / 2, fx, lane);
+            f32x4 kx[8];
+            acc_x<2>(acc, kx);
+#pragma unroll
+            for (int hd = 0; hd < 4; ++hd) store_frag<MODE>(regA, row, hd, h, make_frag<MODE>(kx[2 * hd], kx[2 * hd + 1]));
+        }
+        {   // V -> transposed image [feature][key], keys permuted inside each aligned 32-key tile so that the 8
+            // keys one lane of the A operand needs (16s + 8c + 4h' + e) are contiguous: position (s, h', c, e)
+            f32x16 acc[2];
+            acc_bias<2>(acc, tv + kVBv * kVec64, h, 8);
+            gemm_h<MODE, 4, 2>(acc, Thi + kTbWv / 2, Tlo + kTbWv / 2, fx, lane);
+            const int jj = j;   // key position inside its tile
+            const int kpos = (wave * 4 + ((jj >> 4) & 1) * 2 + ((jj >> 2) & 1)) * 8 + ((jj >> 3) & 1) * 4 + (jj & 3);
+            char* vb = regB + kpos * 2;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int feat = 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
+                    const float v = acc[t][r];
+                    const E vh = (E)v;
+                    *reinterpret_cast<E*>(vb + feat * kVtRowB) = vh;
+                    if (HP<MODE>::kSplit) *reinterpret_cast<E*>(vb + kVtLoOff + feat * kVtRowB) = (E)(v - (float)vh);
+                }
+        }
+        Frag<MODE> fq[4];   // Q operand per head, scaled by 1/sqrt(16)
+        {
+            f32x16 acc[2];
+            acc_bias<2>(acc, tv + kVBq * kVec64, h, 8);
+            gemm_h<MODE, 4, 2>(acc, Thi + kTbWq / 2, Tlo + kTbWq / 2, fx, lane);
+            f32x4 qx[8];
+            acc_x<2>(acc, qx);
+#pragma unroll
+            for (int hd = 0; hd < 4; ++hd) fq[hd] = make_frag<MODE>(qx[2 * hd] * 0.25f, qx[2 * hd + 1] * 0.25f);
+        }
+        __syncthreads();   // K and V^T of the whole tile are in LDS
+
+        f32x4 o[8];        // attention output of this lane's row, chain layout
+#pragma unroll
+        for (int hd = 0; hd < 4; ++hd) {
+            // S^T tiles: rows = keys of tile b_lo+bi, columns = this wave's 32 queries
+            f32x16 st[MAXNB];
+            float m = -3.0e38f;
+#pragma unroll
+            for (int bi = 0; bi < MAXNB; ++bi) {
+                if (bi < nb) {
+                    const Frag<MODE> kf = load_frag<MODE>(regA, 32 * (b_lo + bi) + j, hd, h);
+                    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    mac<MODE>(acc, kf, fq[hd]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float s = (kmask[bi] >> r) & 1u ? acc[r] : -3.0e38f;
+                        acc[r] = s;
+                        m = fmaxf(m, s);
+                    }
+                    st[bi] = acc;
+                }
+            }
+            m = xhalf_max_h(m);
+            float den = 0.f;
+            f32x16 ao = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int bi = 0; bi < MAXNB; ++bi) {
+                if (bi < nb) {
+                    f32x4 p[4];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float e = __expf(st[bi][r] - m);
+                        p[r >> 2][r & 3] = e;
+                        den += e;
+                    }
+                    // O^T (features of head pair hd>>1 x queries) += V^T(tile, step) * P^T(step)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const Frag<MODE> pf = make_frag<MODE>(p[2 * s2], p[2 * s2 + 1]);
+                        const char* vp = regB + (32 * (hd >> 1) + j) * kVtRowB + (((b_lo + bi) * 2 + s2) * 2 + h) * 16;
+                        Frag<MODE> vf;
+                        vf.hi = as_frag<MODE>(*reinterpret_cast<const uint4*>(vp));
+                        if (HP<MODE>::kSplit) vf.lo = as_frag<MODE>(*reinterpret_cast<const uint4*>(vp + kVtLoOff));
+                        mac<MODE>(ao, vf, pf);
+                    }
+                }
+            }
+            const float rden = 1.0f / xhalf_sum_h(den);
+            // rows of ao = features 32*(hd>>1) + 8g + 4h + e; this head owns g = 2*(hd&1), 2*(hd&1)+1
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+                const int g = 2 * (hd & 1) + gg;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[4 * (hd >> 1) + g][e] = ao[4 * g + e] * rden;
+            }
+        }
+
+        // output projection, residual, LayerNorm 1
+        f32x4 hres[8];
+        {
+            Frag<MODE> fo[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fo[ks] = make_frag<MODE>(o[2 * ks], o[2 * ks + 1]);
+            f32x16 acc[2];
+            acc_bias<2>(acc, tv + kVBo * kVec64, h, 8);
+            gemm_h<MODE, 4, 2>(acc, Thi + kTbWo / 2, Tlo + kTbWo / 2, fo, lane);
+            acc_x<2>(acc, hres);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) hres[u] += x1[u];
+            layernorm64_h(hres, tv + kVLn1G * kVec64, tv + kVLn1B * kVec64, h);
+        }
+        // FFN 64 -> 256 (swish) -> 64 in four hidden chunks of 64, residual, LayerNorm 2
+        {
+            Frag<MODE> fh[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fh[ks] = make_frag<MODE>(hres[2 * ks], hres[2 * ks + 1]);
+            f32x16 acc_o[2];
+            acc_bias<2>(acc_o, tv + kVB2 * kVec64, h, 8);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x16 acc_h[2];
+                acc_bias<2>(acc_h, P + To + kTbB1 + 8 * c, h, 32);
+                // ffn1 packed as [8 out tiles][4 k-steps]; this chunk is out tiles 2c, 2c+1
+                gemm_h<MODE, 4, 2>(acc_h, Thi + kTbF1 / 2 + (2 * c) * 4 * 64, Tlo + kTbF1 / 2 + (2 * c) * 4 * 64, fh, lane);
+                f32x4 hid[8];
+                acc_x<2>(acc_h, hid);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hid[u][e] = swish_h(hid[u][e]);
+                // ffn2 packed as [2 out tiles][16 k-steps]; this chunk is k-steps 4c..4c+3
+                Frag<MODE> a2[4][2];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        a2[ks][t] = load_w<MODE>(Thi + kTbF2 / 2, Tlo + kTbF2 / 2, (t * 16 + 4 * c + ks) * 64 + lane);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const Frag<MODE> bf = make_frag<MODE>(hid[2 * ks], hid[2 * ks + 1]);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) mac<MODE>(acc_o[t], a2[ks][t], bf);
+                }
+            }
+            acc_x<2>(acc_o, x1);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x1[u] += hres[u];
+            layernorm64_h(x1, tv + kVLn2G * kVec64, tv + kVLn2B * kVec64, h);
+        }
+    }
+
+    // ---- attention pooling (model.py:176-182), fp32 on the vector units
+    {
+        float part = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const f32x4 wv = P[kOffPoolV + h * 8 + u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part = fmaf(x1[u][e], wv[e], part);
+        }
+        const float sc = tanhf(xhalf_sum_h(part) + P[kOffPoolB][0]);
+        __syncthreads();   // all attention reads of regA are finished
+        float* bufX = reinterpret_cast<float*>(regA);
+        float* xb = bufX + row * kLdsStride + 4 * h;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x4*>(xb + 8 * u) = x1[u];
+        if (h == 0) score[row] = sc;
+        __syncthreads();
+        for (int oi = tid; oi < sites_here * 64; oi += 512) {
+            const int s = oi >> 6, f = oi & 63;
+            const float* sp = score + s * W;
+            float m = sp[0];
+#pragma unroll
+            for (int t = 1; t < W; ++t) m = fmaxf(m, sp[t]);
+            float den = 0.f, acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < W; ++t) {
+                const float e = __expf(sp[t] - m);
+                den += e;
+                acc = fmaf(e, bufX[(s * W + t) * kLdsStride + f], acc);
+            }
+            out[(site0 + s) * ldo + col_off + f] = acc / den;
+        }
+    }
+}
+
+static constexpr size_t kBranchLdsH = 2 * (size_t)kRegionB + kTileRows * sizeof(float);
+
+template <int W, int MODE>
+static hipError_t launch_branch_h_t(const float* params, const void* whi, const void* wlo, const uint8_t* tok, int64_t n,
+                                    float* out, int ldo, int col_off, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&branch_kernel_h<W, MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBranchLdsH);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    constexpr int S = kTileRows / W;
+    const int64_t blocks = (n + S - 1) / S;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL((branch_kernel_h<W, MODE>), dim3((unsigned)blocks), dim3(512), kBranchLdsH, st,
+                       reinterpret_cast<const f32x4*>(params), reinterpret_cast<const uint4*>(whi),
+                       reinterpret_cast<const uint4*>(wlo), tok, n, out, ldo, col_off);
+    return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_branch_h_m(int w, const float* params, const void* whi, const void* wlo, const uint8_t* tok,
+                                    int64_t n, float* out, int ldo, int col_off, hipStream_t st) {
+    switch (w) {
+        case 21: return launch_branch_h_t<21, MODE>(params, whi, wlo, tok, n, out, ldo, col_off, st);
+        case 33: return launch_branch_h_t<33, MODE>(params, whi, wlo, tok, n, out, ldo, col_off, st);
+        case 51: return launch_branch_h_t<51, MODE>(params, whi, wlo, tok, n, out, ldo, col_off, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_branch_h(int mode, int w, const float* params, const void* whi, const void* wlo, const uint8_t* tok,
+                           int64_t n, float* out, int ldo, int col_off, hipStream_t st) {
+    switch (mode) {
+        case kModeBF16: return launch_branch_h_m<kModeBF16>(w, params, whi, wlo, tok, n, out, ldo, col_off, st);
+        case kModeF16: return launch_branch_h_m<kModeF16>(w, params, whi, wlo, tok, n, out, ldo, col_off, st);
+        case kModeF16X3: return launch_branch_h_m<kModeF16X3>(w, params, whi, wlo, tok, n, out, ldo, col_off, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace dptm

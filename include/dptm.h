@@ -140,6 +140,21 @@ enum {
 int dptm_profile_begin(dptm_handle* h);
 int dptm_profile_end(dptm_handle* h, float* ms, int64_t* launches);
 
+/* Arithmetic of the matrix products in the fused sequence branches (the per-site dense
+ * layers always run in fp32).  Everything else -- normalisation, softmax, activations,
+ * accumulation -- is fp32 in every mode.  No counterpart in the reference (Keras runs the
+ * graph in fp32).
+ *   DPTM_PREC_F32    fp32 MFMA (default); probabilities within 1e-4 of the fp32 reference
+ *   DPTM_PREC_BF16   operands rounded to bfloat16
+ *   DPTM_PREC_F16    operands rounded to float16
+ *   DPTM_PREC_F16X3  operands split into two float16 parts, three MFMAs per product:
+ *                    fp32-class accuracy (same 1e-4 bound) on the half-precision matrix cores */
+#define DPTM_PREC_F32 0
+#define DPTM_PREC_BF16 1
+#define DPTM_PREC_F16 2
+#define DPTM_PREC_F16X3 3
+int dptm_set_precision(dptm_handle* h, int mode);
+
 /* Largest number of sites the device-resident calls process per internal pass. */
 int64_t dptm_chunk_sites(const dptm_handle* h);
 

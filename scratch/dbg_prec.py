@@ -1,0 +1,16 @@
+import sys, os
+sys.path.insert(0, os.getcwd())
+import numpy as np
+from deepptmpred_amd import spec
+from deepptmpred_amd.model import Model
+from oracle import ptm_oracle as O
+w = spec.synthetic_weights(7)
+m = Model(w)
+for n in (7, 300, 2000):
+    x = spec.synthetic_inputs(n, 50 + n)
+    with np.errstate(over="ignore"):
+        ref = O.forward(w, x, np.float64)
+    for mode in ("f32", "f16x3", "f16", "bf16"):
+        m.scorer.set_precision(mode)
+        p = m.predict(x)
+        print(n, mode, "max abs err %.3e" % np.abs(p - ref).max(), "finite", np.isfinite(p).all())
