@@ -82,6 +82,7 @@ __device__ __forceinline__ Frag<MODE> load_w(const uint4* __restrict__ hi, const
     return f;
 }
 
+__device__ __forceinline__ float exp2_h(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_rcp_h(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float swish_h(float x) { return x * fast_rcp_h(1.0f + __expf(-x)); }
 __device__ __forceinline__ float xhalf_sum_h(float v) { return v + __shfl_xor(v, 32); }
@@ -154,6 +155,11 @@ constexpr int kLoOff = 256 * kRowB;           // 36,864
 constexpr int kVtRowB = 528;                  // V^T image: [feature][256 keys] x 2 B + 16 B pad
 constexpr int kVtLoOff = 64 * kVtRowB;        // 33,792
 constexpr int kRegionB = 2 * 256 * kRowB;     // 73,728 >= 2*64*528 and >= 256*68*4
+// LDS copy of the branch's vectors: conv (7 x 64) | block 0 (9 x 64 + 256) | block 1 | pooling (64 + 1)
+constexpr int kVecsConv = 7 * kVec64;
+constexpr int kVecsTb = 9 * kVec64 + kVec256;
+constexpr int kVecsF4 = kVecsConv + 2 * kVecsTb + kVec64 + 1;
+static_assert(kTbB1 == kTbVec + 9 * kVec64 && kOffPoolB == kOffPoolV + kVec64, "vector groups must be contiguous");
 
 template <int MODE>
 __device__ __forceinline__ void store_frag(char* region, int row, int slot, int h, const Frag<MODE>& f) {
@@ -178,6 +184,26 @@ __device__ __forceinline__ Frag<MODE> zero_frag() {
     return f;
 }
 
+// Register buffer for the weight fragments of one product: KS k-steps (16 inputs each) x NT out tiles.
+// load(): fragment (t, ks) = index ((t0 + t)*stride + ks0 + ks)*64 + lane of a packed half image whose
+// out tiles are `stride` k-steps apart.
+template <int MODE, int KS, int NT>
+struct WBuf {
+    Frag<MODE> a[KS][NT];
+    __device__ __forceinline__ void load(const uint4* __restrict__ hi, const uint4* __restrict__ lo, int stride, int t0, int ks0, int lane) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a[ks][t] = load_w<MODE>(hi, lo, ((t0 + t) * stride + ks0 + ks) * 64 + lane);
+    }
+    __device__ __forceinline__ void mm(f32x16 (&acc)[NT], const Frag<MODE> (&x)[KS]) const {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) mac<MODE>(acc[t], a[ks][t], x[ks]);
+    }
+};
+
 template <int W, int MODE>
 __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__ P, const uint4* __restrict__ Whi,
                                                        const uint4* __restrict__ Wlo, const uint8_t* __restrict__ tok,
@@ -189,6 +215,9 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
     char* regA = lds_h;                 // X0 fragments | K fragments | final activations (fp32 [256][68])
     char* regB = lds_h + kRegionB;      // y1 fragments | V^T
     float* score = reinterpret_cast<float*>(lds_h + 2 * kRegionB);
+    // bias / scale / LayerNorm vectors of the whole branch, copied once: a vector read costs the texture path
+    // as much as a weight fragment, and there are more of them than weight fragments
+    f32x4* vecs = reinterpret_cast<f32x4*>(lds_h + 2 * kRegionB + kTileRows * sizeof(float));
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -235,6 +264,13 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
         kmask[bi] = bi < nb ? m : 0u;
     }
 
+    for (int i = threadIdx.x; i < kVecsF4; i += 512) {
+        const int src = i < kVecsConv ? kOffConvV + i
+                      : i < kVecsConv + kVecsTb ? kOffTb + kTbVec + (i - kVecsConv)
+                      : i < kVecsConv + 2 * kVecsTb ? kOffTb + kTbSize + kTbVec + (i - kVecsConv - kVecsTb)
+                                                    : kOffPoolV + (i - kVecsConv - 2 * kVecsTb);
+        vecs[i] = P[src];
+    }
     // ---- embedding + position embedding, this lane's row in the chain layout (model.py:157-158)
     f32x4 x1[8];
     {
@@ -257,7 +293,7 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
 
     // ---- residual conv block (model.py:129-141)
     {
-        const f32x4* cv = P + kOffConvV;
+        const f32x4* cv = vecs;
         f32x16 acc_s[2], acc_a[2];
         acc_bias<2>(acc_s, cv + kVScB * kVec64, h, 8);
         acc_bias<2>(acc_a, cv + kVC3aB * kVec64, h, 8);
@@ -318,99 +354,118 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
     }
 
     // ---- two transformer blocks (model.py:93-118, 172-173)
+    // Weight fragments travel through two register buffers (wa, wb) that are refilled one
+    // layer ahead of their use, so the L2 latency of a layer's weights hides behind the
+    // previous layer's MFMAs and epilogue; sched_barrier pins that issue order.
 #pragma unroll 1
     for (int blk = 0; blk < 2; ++blk) {
         const int To = kOffTb + blk * kTbSize;
-        const f32x4* tv = P + To + kTbVec;
+        const f32x4* tv = vecs + kVecsConv + blk * kVecsTb;
         const uint4* Thi = Whi + To / 2;
         const uint4* Tlo = Wlo + To / 2;
+        // K, V, Q projections in pieces of NTQ out tiles (one tile in the split mode, whose fragments are
+        // twice as large); piece u+1 is in flight while piece u multiplies
+        constexpr int NTQ = HP<MODE>::kSplit ? 1 : 2;
+        constexpr int NP = 2 / NTQ;
+        WBuf<MODE, 4, NTQ> wq[2];
+        WBuf<MODE, 4, 2> wo;
+        wq[0].load(Thi + kTbWk / 2, Tlo + kTbWk / 2, 4, 0, 0, lane);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fx[ks] = make_frag<MODE>(x1[2 * ks], x1[2 * ks + 1]);
         __syncthreads();   // every wave is done with regA/regB (conv taps, or the previous block's K / V^T)
-        {   // K -> fragment image [row][head][half]
-            f32x16 acc[2];
-            acc_bias<2>(acc, tv + kVBk * kVec64, h, 8);
-            gemm_h<MODE, 4, 2>(acc, Thi + kTbWk / 2, Tlo + kTbWk / 2, fx, lane);
-            f32x4 kx[8];
-            acc_x<2>(acc, kx);
+        Frag<MODE> fq[4];   // Q operand per head, scaled by log2(e)/sqrt(16): the softmax below works in base 2
 #pragma unroll
-            for (int hd = 0; hd < 4; ++hd) store_frag<MODE>(regA, row, hd, h, make_frag<MODE>(kx[2 * hd], kx[2 * hd + 1]));
-        }
-        {   // V -> transposed image [feature][key], keys permuted inside each aligned 32-key tile so that the 8
-            // keys one lane of the A operand needs (16s + 8c + 4h' + e) are contiguous: position (s, h', c, e)
-            f32x16 acc[2];
-            acc_bias<2>(acc, tv + kVBv * kVec64, h, 8);
-            gemm_h<MODE, 4, 2>(acc, Thi + kTbWv / 2, Tlo + kTbWv / 2, fx, lane);
-            const int jj = j;   // key position inside its tile
-            const int kpos = (wave * 4 + ((jj >> 4) & 1) * 2 + ((jj >> 2) & 1)) * 8 + ((jj >> 3) & 1) * 4 + (jj & 3);
-            char* vb = regB + kpos * 2;
+        for (int u = 0; u < 3 * NP; ++u) {
+            constexpr int kMatOff[3] = {kTbWk, kTbWv, kTbWq};
+            constexpr int kVecOff[3] = {kVBk, kVBv, kVBq};
+            const int pr = u / NP, t0 = (u % NP) * NTQ;
+            if (u + 1 < 3 * NP) {
+                const int pn = (u + 1) / NP, tn = ((u + 1) % NP) * NTQ;
+                wq[(u + 1) & 1].load(Thi + kMatOff[pn] / 2, Tlo + kMatOff[pn] / 2, 4, tn, 0, lane);
+            } else if (!HP<MODE>::kSplit) {
+                wo.load(Thi + kTbWo / 2, Tlo + kTbWo / 2, 4, 0, 0, lane);   // stays in flight across the attention
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 acc[NTQ];
+            acc_bias<NTQ>(acc, tv + kVecOff[pr] * kVec64 + 4 * t0, h, 8);
+            wq[u & 1].mm(acc, fx);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pr == 0) {          // K -> fragment image [row][head][half]
+                f32x4 kx[4 * NTQ];
+                acc_x<NTQ>(acc, kx);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int hd = 0; hd < 2 * NTQ; ++hd)
+                    store_frag<MODE>(regA, row, 2 * t0 + hd, h, make_frag<MODE>(kx[2 * hd], kx[2 * hd + 1]));
+            } else if (pr == 1) {   // V -> transposed image [feature][key], keys permuted inside each aligned
+                // 32-key tile so that the 8 keys one lane of the A operand needs (16s + 8c + 4h' + e) are
+                // contiguous: position (s, h', c, e)
+                const int kpos = (wave * 4 + ((j >> 4) & 1) * 2 + ((j >> 2) & 1)) * 8 + ((j >> 3) & 1) * 4 + (j & 3);
+                char* vb = regB + kpos * 2;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int feat = 32 * t + 8 * (r >> 2) + 4 * h + (r & 3);
-                    const float v = acc[t][r];
-                    const E vh = (E)v;
-                    *reinterpret_cast<E*>(vb + feat * kVtRowB) = vh;
-                    if (HP<MODE>::kSplit) *reinterpret_cast<E*>(vb + kVtLoOff + feat * kVtRowB) = (E)(v - (float)vh);
-                }
-        }
-        Frag<MODE> fq[4];   // Q operand per head, scaled by 1/sqrt(16)
-        {
-            f32x16 acc[2];
-            acc_bias<2>(acc, tv + kVBq * kVec64, h, 8);
-            gemm_h<MODE, 4, 2>(acc, Thi + kTbWq / 2, Tlo + kTbWq / 2, fx, lane);
-            f32x4 qx[8];
-            acc_x<2>(acc, qx);
+                for (int t = 0; t < NTQ; ++t)
 #pragma unroll
-            for (int hd = 0; hd < 4; ++hd) fq[hd] = make_frag<MODE>(qx[2 * hd] * 0.25f, qx[2 * hd + 1] * 0.25f);
+                    for (int r = 0; r < 16; ++r) {
+                        const int feat = 32 * (t0 + t) + 8 * (r >> 2) + 4 * h + (r & 3);
+                        const float v = acc[t][r];
+                        const E vh = (E)v;
+                        *reinterpret_cast<E*>(vb + feat * kVtRowB) = vh;
+                        if (HP<MODE>::kSplit) *reinterpret_cast<E*>(vb + kVtLoOff + feat * kVtRowB) = (E)(v - (float)vh);
+                    }
+            } else {
+                f32x4 qx[4 * NTQ];
+                acc_x<NTQ>(acc, qx);
+                constexpr float kQScale = 0.25f * 1.4426950408889634f;
+#pragma unroll
+                for (int hd = 0; hd < 2 * NTQ; ++hd) fq[2 * t0 + hd] = make_frag<MODE>(qx[2 * hd] * kQScale, qx[2 * hd + 1] * kQScale);
+            }
         }
         __syncthreads();   // K and V^T of the whole tile are in LDS
 
+        // attention, one head at a time, keys walked in aligned 32-key tiles with a running maximum
         f32x4 o[8];        // attention output of this lane's row, chain layout
 #pragma unroll
         for (int hd = 0; hd < 4; ++hd) {
-            // S^T tiles: rows = keys of tile b_lo+bi, columns = this wave's 32 queries
-            f32x16 st[MAXNB];
-            float m = -3.0e38f;
+            float m = -3.0e38f, den = 0.f;
+            f32x16 ao = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            Frag<MODE> kf = load_frag<MODE>(regA, 32 * b_lo + j, hd, h);
 #pragma unroll
             for (int bi = 0; bi < MAXNB; ++bi) {
                 if (bi < nb) {
-                    const Frag<MODE> kf = load_frag<MODE>(regA, 32 * (b_lo + bi) + j, hd, h);
-                    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    mac<MODE>(acc, kf, fq[hd]);
+                    // S^T tile: rows = keys of tile b_lo+bi, columns = this wave's 32 queries
+                    f32x16 st = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    mac<MODE>(st, kf, fq[hd]);
+                    // operands of the next steps are fetched while the MFMA runs
+                    const char* vp = regB + (32 * (hd >> 1) + j) * kVtRowB + ((b_lo + bi) * 4 + h) * 16;
+                    Frag<MODE> vf0, vf1;
+                    vf0.hi = as_frag<MODE>(*reinterpret_cast<const uint4*>(vp));
+                    vf1.hi = as_frag<MODE>(*reinterpret_cast<const uint4*>(vp + 32));
+                    if (HP<MODE>::kSplit) {
+                        vf0.lo = as_frag<MODE>(*reinterpret_cast<const uint4*>(vp + kVtLoOff));
+                        vf1.lo = as_frag<MODE>(*reinterpret_cast<const uint4*>(vp + kVtLoOff + 32));
+                    }
+                    if (bi + 1 < MAXNB && bi + 1 < nb) kf = load_frag<MODE>(regA, 32 * (b_lo + bi + 1) + j, hd, h);
+                    float tm = -3.0e38f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float s = (kmask[bi] >> r) & 1u ? acc[r] : -3.0e38f;
-                        acc[r] = s;
-                        m = fmaxf(m, s);
+                        const float sv = (kmask[bi] >> r) & 1u ? st[r] : -3.0e38f;
+                        st[r] = sv;
+                        tm = fmaxf(tm, sv);
                     }
-                    st[bi] = acc;
-                }
-            }
-            m = xhalf_max_h(m);
-            float den = 0.f;
-            f32x16 ao = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int bi = 0; bi < MAXNB; ++bi) {
-                if (bi < nb) {
+                    const float mn = fmaxf(m, xhalf_max_h(tm));
+                    const float alpha = exp2_h(m - mn);
+                    m = mn;
+                    den *= alpha;
+                    ao *= alpha;
                     f32x4 p[4];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float e = __expf(st[bi][r] - m);
+                        const float e = exp2_h(st[r] - mn);
                         p[r >> 2][r & 3] = e;
                         den += e;
                     }
                     // O^T (features of head pair hd>>1 x queries) += V^T(tile, step) * P^T(step)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        const Frag<MODE> pf = make_frag<MODE>(p[2 * s2], p[2 * s2 + 1]);
-                        const char* vp = regB + (32 * (hd >> 1) + j) * kVtRowB + (((b_lo + bi) * 2 + s2) * 2 + h) * 16;
-                        Frag<MODE> vf;
-                        vf.hi = as_frag<MODE>(*reinterpret_cast<const uint4*>(vp));
-                        if (HP<MODE>::kSplit) vf.lo = as_frag<MODE>(*reinterpret_cast<const uint4*>(vp + kVtLoOff));
-                        mac<MODE>(ao, vf, pf);
-                    }
+                    mac<MODE>(ao, vf0, make_frag<MODE>(p[0], p[1]));
+                    mac<MODE>(ao, vf1, make_frag<MODE>(p[2], p[3]));
                 }
             }
             const float rden = 1.0f / xhalf_sum_h(den);
@@ -424,51 +479,59 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
         }
 
         // output projection, residual, LayerNorm 1
+        // FFN 64 -> 256 (swish) -> 64 walks the hidden units in chunks of HT 32-wide tiles (one tile in the
+        // split mode, whose fragments are twice as large), residual, LayerNorm 2
+        constexpr int HT = HP<MODE>::kSplit ? 1 : 2;
+        WBuf<MODE, 4, HT> w1;          // ffn1 packed [8 out tiles][4 k-steps]: chunk c = out tiles HT*c ..
+        WBuf<MODE, 2 * HT, 2> w2;      // ffn2 packed [2 out tiles][16 k-steps]: chunk c = k-steps 2*HT*c ..
         f32x4 hres[8];
         {
             Frag<MODE> fo[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) fo[ks] = make_frag<MODE>(o[2 * ks], o[2 * ks + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (HP<MODE>::kSplit) wo.load(Thi + kTbWo / 2, Tlo + kTbWo / 2, 4, 0, 0, lane);    // no registers to spare earlier
+            w1.load(Thi + kTbF1 / 2, Tlo + kTbF1 / 2, 4, 0, 0, lane);
+            __builtin_amdgcn_sched_barrier(0);
             f32x16 acc[2];
             acc_bias<2>(acc, tv + kVBo * kVec64, h, 8);
-            gemm_h<MODE, 4, 2>(acc, Thi + kTbWo / 2, Tlo + kTbWo / 2, fo, lane);
+            wo.mm(acc, fo);
+            __builtin_amdgcn_sched_barrier(0);
+            w2.load(Thi + kTbF2 / 2, Tlo + kTbF2 / 2, 16, 0, 0, lane);
+            __builtin_amdgcn_sched_barrier(0);
             acc_x<2>(acc, hres);
 #pragma unroll
             for (int u = 0; u < 8; ++u) hres[u] += x1[u];
             layernorm64_h(hres, tv + kVLn1G * kVec64, tv + kVLn1B * kVec64, h);
         }
-        // FFN 64 -> 256 (swish) -> 64 in four hidden chunks of 64, residual, LayerNorm 2
         {
             Frag<MODE> fh[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) fh[ks] = make_frag<MODE>(hres[2 * ks], hres[2 * ks + 1]);
             f32x16 acc_o[2];
             acc_bias<2>(acc_o, tv + kVB2 * kVec64, h, 8);
+            constexpr int NCH = 8 / HT;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                f32x16 acc_h[2];
-                acc_bias<2>(acc_h, P + To + kTbB1 + 8 * c, h, 32);
-                // ffn1 packed as [8 out tiles][4 k-steps]; this chunk is out tiles 2c, 2c+1
-                gemm_h<MODE, 4, 2>(acc_h, Thi + kTbF1 / 2 + (2 * c) * 4 * 64, Tlo + kTbF1 / 2 + (2 * c) * 4 * 64, fh, lane);
-                f32x4 hid[8];
-                acc_x<2>(acc_h, hid);
+            for (int c = 0; c < NCH; ++c) {
+                f32x16 acc_h[HT];
+                acc_bias<HT>(acc_h, tv + 9 * kVec64 + 4 * HT * c, h, 32);
+                w1.mm(acc_h, fh);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c + 1 < NCH) w1.load(Thi + kTbF1 / 2, Tlo + kTbF1 / 2, 4, HT * (c + 1), 0, lane);
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 hid[4 * HT];
+                acc_x<HT>(acc_h, hid);
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < 4 * HT; ++u)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) hid[u][e] = swish_h(hid[u][e]);
-                // ffn2 packed as [2 out tiles][16 k-steps]; this chunk is k-steps 4c..4c+3
-                Frag<MODE> a2[4][2];
+                Frag<MODE> fhid[2 * HT];
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-                        a2[ks][t] = load_w<MODE>(Thi + kTbF2 / 2, Tlo + kTbF2 / 2, (t * 16 + 4 * c + ks) * 64 + lane);
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const Frag<MODE> bf = make_frag<MODE>(hid[2 * ks], hid[2 * ks + 1]);
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) mac<MODE>(acc_o[t], a2[ks][t], bf);
-                }
+                for (int ks = 0; ks < 2 * HT; ++ks) fhid[ks] = make_frag<MODE>(hid[2 * ks], hid[2 * ks + 1]);
+                w2.mm(acc_o, fhid);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c + 1 < NCH) w2.load(Thi + kTbF2 / 2, Tlo + kTbF2 / 2, 16, 0, 2 * HT * (c + 1), lane);
+                __builtin_amdgcn_sched_barrier(0);
             }
             acc_x<2>(acc_o, x1);
 #pragma unroll
@@ -482,11 +545,11 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
         float part = 0.f;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const f32x4 wv = P[kOffPoolV + h * 8 + u];
+            const f32x4 wv = vecs[kVecsConv + 2 * kVecsTb + h * 8 + u];
 #pragma unroll
             for (int e = 0; e < 4; ++e) part = fmaf(x1[u][e], wv[e], part);
         }
-        const float sc = tanhf(xhalf_sum_h(part) + P[kOffPoolB][0]);
+        const float sc = tanhf(xhalf_sum_h(part) + vecs[kVecsConv + 2 * kVecsTb + kVec64][0]);
         __syncthreads();   // all attention reads of regA are finished
         float* bufX = reinterpret_cast<float*>(regA);
         float* xb = bufX + row * kLdsStride + 4 * h;
@@ -512,7 +575,7 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
     }
 }
 
-static constexpr size_t kBranchLdsH = 2 * (size_t)kRegionB + kTileRows * sizeof(float);
+static constexpr size_t kBranchLdsH = 2 * (size_t)kRegionB + kTileRows * sizeof(float) + kVecsF4 * 16;
 
 template <int W, int MODE>
 static hipError_t launch_branch_h_t(const float* params, const void* whi, const void* wlo, const uint8_t* tok, int64_t n,
