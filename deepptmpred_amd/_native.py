@@ -238,6 +238,8 @@ class Scorer:
     def set_precision(self, mode) -> None:
         """mode: 'f32' | 'bf16' | 'f16' | 'f16x3' (or the DPTM_PREC_* integer)."""
         if isinstance(mode, str):
+            if mode.lower() not in PRECISIONS:
+                raise ValueError("unknown precision %r (one of %s)" % (mode, ", ".join(PRECISIONS)))
             mode = PRECISIONS[mode.lower()]
         _check(self._lib, self._lib.dptm_set_precision(self._h, int(mode)), "dptm_set_precision")
 

@@ -128,6 +128,7 @@ struct DenseLayer {
     float* d_bias = nullptr;
     float* d_scale = nullptr;
     float* d_shift = nullptr;
+    uint16_t* d_w_half[3] = {nullptr, nullptr, nullptr};   // bf16 | f16 hi | f16 lo images (k % 16 == 0, n % 128 == 0 only)
 };
 
 struct ProfRec {
@@ -264,9 +265,18 @@ int make_dense(Reader& rd, int K, int N, int n_pad, bool bn, DenseLayer& L) {
     L.n = N;
     L.n_pad = n_pad;
     std::vector<float> w((size_t)K * n_pad), v((size_t)n_pad);
-    pack_matrix(rd.take((size_t)K * N), K, N, n_pad, w.data());
+    const float* Wm = rd.take((size_t)K * N);
+    pack_matrix(Wm, K, N, n_pad, w.data());
     int rc = upload(w, &L.d_w);
     if (rc) return rc;
+    if (K % 16 == 0 && N == n_pad && N % 128 == 0) {
+        std::vector<uint16_t> hw((size_t)K * N);
+        for (int kind = 0; kind < 3; ++kind) {
+            pack_matrix_half(Wm, K, N, kind, hw.data());
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&L.d_w_half[kind]), hw.size() * sizeof(uint16_t)));
+            HIP_TRY(hipMemcpy(L.d_w_half[kind], hw.data(), hw.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        }
+    }
     pack_vector(rd.take(N), N, n_pad, v.data());
     rc = upload(v, &L.d_bias);
     if (rc) return rc;
@@ -290,6 +300,8 @@ void free_dense(DenseLayer& L) {
     if (L.d_bias) (void)hipFree(L.d_bias);
     if (L.d_scale) (void)hipFree(L.d_scale);
     if (L.d_shift) (void)hipFree(L.d_shift);
+    for (auto* pw : L.d_w_half)
+        if (pw) (void)hipFree(pw);
     L = DenseLayer();
 }
 
@@ -331,7 +343,11 @@ int run_dense(dptm_handle* h, const DenseLayer& L, int epi, const float* x, int6
     a.ldo = ldo;
     a.col_off = col_off;
     Prof p(h, st, cls);
-    HIP_TRY(launch_dense(a, epi, st));
+    if (h->precision != kModeF32 && L.d_w_half[0] && epi != kEpiHead) {
+        HIP_TRY(launch_dense_h(h->precision, a, epi, L.d_w_half[h->precision == kModeBF16 ? 0 : 1], L.d_w_half[2], st));
+    } else {
+        HIP_TRY(launch_dense(a, epi, st));   // fp32: the 8-feature structure layer, the 2-class head
+    }
     return DPTM_OK;
 }
 

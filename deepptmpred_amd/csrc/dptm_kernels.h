@@ -35,6 +35,8 @@ hipError_t launch_branch(int w, const float* params, const uint8_t* tok, int64_t
 hipError_t launch_branch_h(int mode, int w, const float* params, const void* whi, const void* wlo, const uint8_t* tok,
                            int64_t n, float* out, int ldo, int col_off, hipStream_t st);
 hipError_t launch_dense(const DenseArgs& a, int epi, hipStream_t st);
+// half-precision-MFMA dense layer (swish epilogues only; k a multiple of 16): whi/wlo = packed half images of a.w
+hipError_t launch_dense_h(int mode, const DenseArgs& a, int epi, const void* whi, const void* wlo, hipStream_t st);
 hipError_t launch_assemble(const uint8_t* codes, int64_t L, int64_t esm_rows,
                            const int32_t* positions, int64_t n, uint8_t* t21, uint8_t* t33,
                            uint8_t* t51, int32_t* esm_row, hipStream_t st);

@@ -263,6 +263,9 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
         }
         kmask[bi] = bi < nb ? m : 0u;
     }
+#ifdef ABL_H_NB
+    nb = min(nb, ABL_H_NB);
+#endif
 
     for (int i = threadIdx.x; i < kVecsF4; i += 512) {
         const int src = i < kVecsConv ? kOffConvV + i
@@ -468,6 +471,9 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
                     mac<MODE>(ao, vf1, make_frag<MODE>(p[2], p[3]));
                 }
             }
+#ifdef ABL_H_NB
+            den += 1.0f;
+#endif
             const float rden = 1.0f / xhalf_sum_h(den);
             // rows of ao = features 32*(hd>>1) + 8g + 4h + e; this head owns g = 2*(hd&1), 2*(hd&1)+1
 #pragma unroll
@@ -510,7 +516,11 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
             for (int ks = 0; ks < 4; ++ks) fh[ks] = make_frag<MODE>(hres[2 * ks], hres[2 * ks + 1]);
             f32x16 acc_o[2];
             acc_bias<2>(acc_o, tv + kVB2 * kVec64, h, 8);
+#ifdef ABL_H_NOFFN
+            constexpr int NCH = 0;
+#else
             constexpr int NCH = 8 / HT;
+#endif
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 f32x16 acc_h[HT];
@@ -572,6 +582,133 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
             }
             out[(site0 + s) * ldo + col_off + f] = acc / den;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Per-site dense layer on the half-precision MFMA: out[r][col_off + n] = epi(sum_k X[src(r)][k] W[k][n] + b[n]).
+// Same tiling as dense_kernel in dptm_kernels.hip (one wavefront = 64 rows x NT*32 columns, four wavefronts
+// of a workgroup share the weight stream of one column slab); X stays fp32 in memory and is rounded (or
+// split) to operand fragments on the way in, so the layers around it keep their fp32 buffers.
+// ------------------------------------------------------------------------------------
+template <int NT, int EPI, int MODE>
+__global__ __launch_bounds__(256, 2) void dense_kernel_h(DenseArgs p, const uint4* __restrict__ whi, const uint4* __restrict__ wlo) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    if (r0 >= p.m) return;
+    const int slab = blockIdx.y;
+    const int KS = p.k >> 4;
+    const size_t wbase = (size_t)slab * NT * KS * 64 + lane;
+
+    const float* xrow[2];
+    bool ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int64_t r = r0 + 32 * i + j;
+        if (r > p.m - 1) r = p.m - 1;
+        int64_t src = r;
+        ok[i] = true;
+        if (p.row_index) {
+            const int32_t s = p.row_index[r];
+            ok[i] = s >= 0;
+            src = s >= 0 ? s : 0;
+        }
+        xrow[i] = p.x + src * p.ldx + 4 * h;
+    }
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = p.bias[h * (p.n_pad >> 3) + slab * NT * 4 + 4 * t + g];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][t][4 * g + e] = b[e];
+                acc[1][t][4 * g + e] = b[e];
+            }
+        }
+
+    Frag<MODE> a_n[NT];
+    f32x4 b_n[2][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) a_n[t] = load_w<MODE>(whi + wbase, wlo + wbase, t * KS * 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        b_n[i][0] = *reinterpret_cast<const f32x4*>(xrow[i]);
+        b_n[i][1] = *reinterpret_cast<const f32x4*>(xrow[i] + 8);
+    }
+    for (int ks = 0; ks < KS; ++ks) {
+        Frag<MODE> a[NT], b[2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[t] = a_n[t];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            b[i] = make_frag<MODE>(ok[i] ? b_n[i][0] : z, ok[i] ? b_n[i][1] : z);
+        }
+        if (ks + 1 < KS) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a_n[t] = load_w<MODE>(whi + wbase, wlo + wbase, (t * KS + ks + 1) * 64);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                b_n[i][0] = *reinterpret_cast<const f32x4*>(xrow[i] + 16 * (ks + 1));
+                b_n[i][1] = *reinterpret_cast<const f32x4*>(xrow[i] + 16 * (ks + 1) + 8);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            mac<MODE>(acc[0][t], a[t], b[0]);
+            mac<MODE>(acc[1][t], a[t], b[1]);
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t r = r0 + 32 * i + j;
+        if (r >= p.m) continue;
+        float* orow = p.out + r * p.ldo + p.col_off + slab * NT * 32 + 4 * h;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[i][t][4 * g], acc[i][t][4 * g + 1], acc[i][t][4 * g + 2], acc[i][t][4 * g + 3]};
+                const int vi = h * (p.n_pad >> 3) + slab * NT * 4 + 4 * t + g;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = swish_h(v[e]);
+                if (EPI == kEpiSwishAffine) {
+                    const f32x4 sc = p.scale[vi], sh = p.shift[vi];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+                }
+                *reinterpret_cast<f32x4*>(orow + 32 * t + 8 * g) = v;
+            }
+    }
+}
+
+template <int MODE>
+static hipError_t launch_dense_h_m(const DenseArgs& a, int epi, const void* whi, const void* wlo, hipStream_t st) {
+    const unsigned gx = (unsigned)((a.m + 255) / 256), gy = (unsigned)(a.n_pad / 128);
+    const uint4* hi = reinterpret_cast<const uint4*>(whi);
+    const uint4* lo = reinterpret_cast<const uint4*>(wlo);
+    if (epi == kEpiSwish)
+        hipLaunchKernelGGL((dense_kernel_h<4, kEpiSwish, MODE>), dim3(gx, gy), dim3(256), 0, st, a, hi, lo);
+    else if (epi == kEpiSwishAffine)
+        hipLaunchKernelGGL((dense_kernel_h<4, kEpiSwishAffine, MODE>), dim3(gx, gy), dim3(256), 0, st, a, hi, lo);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_dense_h(int mode, const DenseArgs& a, int epi, const void* whi, const void* wlo, hipStream_t st) {
+    if (a.m == 0) return hipSuccess;
+    if (a.n_pad % 128 != 0 || a.k % 16 != 0) return hipErrorInvalidValue;
+    switch (mode) {
+        case kModeBF16: return launch_dense_h_m<kModeBF16>(a, epi, whi, wlo, st);
+        case kModeF16: return launch_dense_h_m<kModeF16>(a, epi, whi, wlo, st);
+        case kModeF16X3: return launch_dense_h_m<kModeF16X3>(a, epi, whi, wlo, st);
+        default: return hipErrorInvalidValue;
     }
 }
 

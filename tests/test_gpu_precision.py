@@ -1,0 +1,96 @@
+"""Half-precision-MFMA modes of the HIP path against the CPU oracle (through the C ABI).
+
+"f16x3" (operands split into two float16 values, three MFMAs per product, fp32 accumulation)
+must meet the same 1e-4 bound on probabilities as the fp32 path.  "f16" and "bf16" round every
+operand once; their bounds below are looser and stated per mode -- they are opt-in speed modes,
+not parity modes."""
+import numpy as np
+import pytest
+
+from deepptmpred_amd import spec
+from deepptmpred_amd.model import Model
+from oracle import ptm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+# absolute bound on probabilities, per mode
+BOUND = {"f32": 1e-4, "f16x3": 1e-4, "f16": 1e-2, "bf16": 6e-2}
+
+
+def oracle(weights, x):
+    with np.errstate(over="ignore"):
+        return O.forward(weights, x, np.float64)
+
+
+@pytest.fixture(scope="module")
+def weights():
+    return spec.synthetic_weights(7)
+
+
+@pytest.fixture()
+def model(weights):
+    m = Model(weights)
+    yield m
+    m.close()
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "f16", "bf16"])
+@pytest.mark.parametrize("n", [1, 5, 13, 257, 2000])
+def test_mode_vs_oracle(model, weights, mode, n):
+    x = spec.synthetic_inputs(n, 4000 + n)
+    ref = oracle(weights, x)
+    model.scorer.set_precision(mode)
+    p = model.predict(x)
+    err = np.abs(p - ref).max()
+    print(mode, n, "max abs err %.3e" % err)
+    assert np.isfinite(p).all()
+    assert err < BOUND[mode]
+    assert np.allclose(p.sum(axis=1), 1.0, atol=1e-6)
+
+
+def test_f16x3_meets_parity_bound_on_other_weights():
+    for seed in (100, 101):
+        w = spec.synthetic_weights(seed)
+        m = Model(w)
+        m.scorer.set_precision("f16x3")
+        x = spec.synthetic_inputs(300, seed)
+        assert np.abs(m.predict(x) - oracle(w, x)).max() < BOUND["f16x3"]
+        m.close()
+
+
+def test_f16x3_edges_and_padding(model, weights):
+    x = spec.synthetic_inputs(16, 8)
+    x[0][:] = 20; x[1][:] = 20; x[2][:] = 20           # every window entirely '*'
+    x[3][:] = np.array([0.5, 0, 0, 0, 1, 0, 85, 85], dtype=np.float32)   # predict.py:526
+    x[4][:8] = 0.0                                      # missing-ESM rows (predict.py:500)
+    model.scorer.set_precision("f16x3")
+    assert np.abs(model.predict(x) - oracle(weights, x)).max() < BOUND["f16x3"]
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "bf16"])
+def test_mode_rows_independent(model, mode):
+    """Per-site scoring in every mode.  A prefix of the batch keeps every site at the same place of
+    its 256-row tile, so its rows are bit-identical; a permutation moves sites to other offsets of
+    the aligned 32-key attention tiles, which changes the fp32 summation order only."""
+    model.scorer.set_precision(mode)
+    n = 3000
+    x = spec.synthetic_inputs(n, 78)
+    p = model.predict(x)
+    assert np.array_equal(model.predict([a[:777] for a in x]), p[:777])
+    perm = np.random.default_rng(1).permutation(n)
+    q = model.predict([a[perm] for a in x])
+    d = np.abs(q - p[perm]).max()
+    print(mode, "max abs difference under permutation %.3e" % d)
+    assert d < (2e-5 if mode == "f16x3" else BOUND[mode])
+
+
+def test_mode_switch_round_trip(model, weights):
+    """Switching modes on one handle leaves the fp32 results bit-identical."""
+    x = spec.synthetic_inputs(100, 5)
+    a = model.predict(x)
+    model.scorer.set_precision("bf16")
+    model.predict(x)
+    model.scorer.set_precision("f32")
+    assert np.array_equal(model.predict(x), a)
+    with pytest.raises(ValueError):
+        model.scorer.set_precision("fp8")
