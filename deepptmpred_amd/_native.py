@@ -92,6 +92,16 @@ def load_library() -> C.CDLL:
         raise NativeLibraryError(
             f"{_LIB_PATH} is missing: build it with `make -C deepptmpred_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    # PyTorch wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1.  A process can drive the
+    # GPU through one ROCm runtime only: if libdptm.so pulled in the system copy first, a later
+    # `import torch` would load the bundled one as a second runtime and find no GPU.  Loading torch
+    # first makes libdptm.so bind to the runtime torch uses (same sonames), so device pointers of torch
+    # tensors are valid in both.  DPTM_NO_TORCH_PRELOAD=1 skips this for torch-free processes.
+    if not os.environ.get("DPTM_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     try:
         lib = C.CDLL(_LIB_PATH)
     except OSError as e:  # pragma: no cover - depends on the machine

@@ -145,6 +145,9 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
     float* bufA = lds;
     float* bufB = lds + kTileRows * kLdsStride;
     float* score = bufB + kTileRows * kLdsStride;  // [256]
+    // bias / scale / LayerNorm vectors of the whole branch, copied once per workgroup: read from
+    // memory they cost the texture path as many instructions as the weight fragments do
+    f32x4* vecs = reinterpret_cast<f32x4*>(score + kTileRows);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -155,6 +158,7 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
     const int sites_here = (int)min((int64_t)S, n_sites - site0);
     const int rows_valid = sites_here * W;
 
+    for (int i = tid; i < kVecsF4; i += 512) vecs[i] = P[vecs_source(i)];
     // ---- embedding + position embedding -> bufA   (model.py:157-158)
     for (int idx = tid; idx < kTileRows * 16; idx += 512) {
         const int r = idx >> 4, c4 = idx & 15;
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
 
     // ---- residual conv block (model.py:129-141)
     {
-        const f32x4* cv = P + kOffConvV;
+        const f32x4* cv = vecs;
         f32x16 acc_s[2], acc_a[2];
         acc_init_bias<2>(acc_s, cv + kVScB * kVec64, h, 8);
         acc_init_bias<2>(acc_a, cv + kVC3aB * kVec64, h, 8);
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
 #pragma unroll 1
     for (int blk = 0; blk < 2; ++blk) {
         const f32x4* T = P + kOffTb + blk * kTbSize;
-        const f32x4* tv = T + kTbVec;
+        const f32x4* tv = vecs + kVecsConv + blk * kVecsTb;
         // every wave is done reading bufA/bufB (conv taps, or the previous block's K/V)
         __syncthreads();
         {
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
             for (int c = 0; c < 4; ++c) {
                 f32x16 acc_h[2];
                 // hidden tiles 2c, 2c+1 <-> bias groups 8c..8c+7 of the 256-vector
-                acc_init_bias<2>(acc_h, T + kTbB1 + 8 * c, h, 32);
+                acc_init_bias<2>(acc_h, tv + 9 * kVec64 + 8 * c, h, 32);
                 gemm_regs<8, 2, 2>(acc_h, T + kTbF1 + (2 * c) * 8 * 64, hres, lane);
                 f32x4 hid[8];
                 acc_to_x<2>(acc_h, hid);
@@ -451,11 +455,11 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
         float part = 0.f;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const f32x4 wv = P[kOffPoolV + h * 8 + u];
+            const f32x4 wv = vecs[kVecsPool + h * 8 + u];
 #pragma unroll
             for (int e = 0; e < 4; ++e) part = fmaf(x1[u][e], wv[e], part);
         }
-        const float sc = tanhf(xhalf_sum(part) + P[kOffPoolB][0]);
+        const float sc = tanhf(xhalf_sum(part) + vecs[kVecsPool + kVec64][0]);
         __syncthreads();  // all attention reads of bufA are finished
         float* xb = bufA + row * kLdsStride + 4 * h;
 #pragma unroll
@@ -631,7 +635,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(const uint8_t* __restrict
 
 // ------------------------------------------------------------------------------------ launchers
 
-static constexpr size_t kBranchLds = (2 * kTileRows * kLdsStride + kTileRows) * sizeof(float);
+static constexpr size_t kBranchLds = (2 * kTileRows * kLdsStride + kTileRows) * sizeof(float) + kVecsF4 * 16;
 
 template <int W>
 static hipError_t launch_branch_t(const float* params, const uint8_t* tok, int64_t n, float* out,

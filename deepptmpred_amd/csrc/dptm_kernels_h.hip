@@ -155,11 +155,6 @@ constexpr int kLoOff = 256 * kRowB;           // 36,864
 constexpr int kVtRowB = 528;                  // V^T image: [feature][256 keys] x 2 B + 16 B pad
 constexpr int kVtLoOff = 64 * kVtRowB;        // 33,792
 constexpr int kRegionB = 2 * 256 * kRowB;     // 73,728 >= 2*64*528 and >= 256*68*4
-// LDS copy of the branch's vectors: conv (7 x 64) | block 0 (9 x 64 + 256) | block 1 | pooling (64 + 1)
-constexpr int kVecsConv = 7 * kVec64;
-constexpr int kVecsTb = 9 * kVec64 + kVec256;
-constexpr int kVecsF4 = kVecsConv + 2 * kVecsTb + kVec64 + 1;
-static_assert(kTbB1 == kTbVec + 9 * kVec64 && kOffPoolB == kOffPoolV + kVec64, "vector groups must be contiguous");
 
 template <int MODE>
 __device__ __forceinline__ void store_frag(char* region, int row, int slot, int h, const Frag<MODE>& f) {
@@ -267,13 +262,7 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
     nb = min(nb, ABL_H_NB);
 #endif
 
-    for (int i = threadIdx.x; i < kVecsF4; i += 512) {
-        const int src = i < kVecsConv ? kOffConvV + i
-                      : i < kVecsConv + kVecsTb ? kOffTb + kTbVec + (i - kVecsConv)
-                      : i < kVecsConv + 2 * kVecsTb ? kOffTb + kTbSize + kTbVec + (i - kVecsConv - kVecsTb)
-                                                    : kOffPoolV + (i - kVecsConv - 2 * kVecsTb);
-        vecs[i] = P[src];
-    }
+    for (int i = threadIdx.x; i < kVecsF4; i += 512) vecs[i] = P[vecs_source(i)];
     // ---- embedding + position embedding, this lane's row in the chain layout (model.py:157-158)
     f32x4 x1[8];
     {
@@ -555,11 +544,11 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
         float part = 0.f;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const f32x4 wv = vecs[kVecsConv + 2 * kVecsTb + h * 8 + u];
+            const f32x4 wv = vecs[kVecsPool + h * 8 + u];
 #pragma unroll
             for (int e = 0; e < 4; ++e) part = fmaf(x1[u][e], wv[e], part);
         }
-        const float sc = tanhf(xhalf_sum_h(part) + vecs[kVecsConv + 2 * kVecsTb + kVec64][0]);
+        const float sc = tanhf(xhalf_sum_h(part) + vecs[kVecsPool + kVec64][0]);
         __syncthreads();   // all attention reads of regA are finished
         float* bufX = reinterpret_cast<float*>(regA);
         float* xb = bufX + row * kLdsStride + 4 * h;

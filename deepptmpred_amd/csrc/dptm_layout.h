@@ -69,4 +69,18 @@ constexpr int kOffPoolV = kOffTb + 2 * kTbSize;         // pooling weight vector
 constexpr int kOffPoolB = kOffPoolV + kVec64;           // pooling bias in .x
 constexpr int kBranchF4 = kOffPoolB + 1;
 
+// LDS copy of a branch's bias / scale / LayerNorm vectors (float4 units): conv (7 x 64) | block 0
+// (9 x 64 + 256) | block 1 | pooling (64 + 1).  vecs_source(i) = float4 index in the packed buffer.
+constexpr int kVecsConv = 7 * kVec64;
+constexpr int kVecsTb = 9 * kVec64 + kVec256;
+constexpr int kVecsPool = kVecsConv + 2 * kVecsTb;
+constexpr int kVecsF4 = kVecsPool + kVec64 + 1;
+static_assert(kTbB1 == kTbVec + 9 * kVec64 && kOffPoolB == kOffPoolV + kVec64, "vector groups must be contiguous");
+constexpr int vecs_source(int i) {
+    return i < kVecsConv ? kOffConvV + i
+         : i < kVecsConv + kVecsTb ? kOffTb + kTbVec + (i - kVecsConv)
+         : i < kVecsPool ? kOffTb + kTbSize + kTbVec + (i - kVecsConv - kVecsTb)
+                         : kOffPoolV + (i - kVecsPool);
+}
+
 }  // namespace dptm
