@@ -36,6 +36,27 @@ FLOPS_PER_SITE = 31_234_816          # 2*MAC of every contraction of the forward
 FLOPS_BRANCH = {21: 5_564_160, 33: 8_946_432, 51: 14_296_320}
 BYTES_PER_SITE = 5_261               # 1280*4 + 8*4 + 105 + 4
 PEAK_F32_MFMA_TFLOPS = 157.3         # dense fp32 matrix peak of MI355X
+PEAK_F16_MFMA_TFLOPS = 2500.0        # dense f16 / bf16 matrix peak (no sparsity)
+PEAK_MFMA = {"f32": PEAK_F32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS, "f16": PEAK_F16_MFMA_TFLOPS,
+             "bf16": PEAK_F16_MFMA_TFLOPS}
+KERNEL_NAME = {"f32": "branch_kernel<51>", "f16x3": "branch_kernel_h<51,f16x3>", "f16": "branch_kernel_h<51,f16>",
+               "bf16": "branch_kernel_h<51,bf16>"}
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+
+
+def measured_traffic(precision: str, sites_per_launch: float):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/collect_pmc.sh: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction for 16 B/lane
+    reads).  PMC counters cannot be read from inside this process; null when no pass was recorded
+    for this precision and launch size."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            rec = json.load(f).get(precision)
+    except (OSError, ValueError):
+        return None
+    if not rec or abs(rec.get("sites_per_launch", 0) - sites_per_launch) > 0.5:
+        return None
+    return rec.get("traffic_bytes_per_launch")
 PEAK_HBM_GBS = 8000.0
 
 
@@ -170,6 +191,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--sites", type=int, default=1_000_000, help="sites per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the short extra measurement of the other precision modes")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16x3", "f16", "bf16"],
                     help="arithmetic of the sequence-branch matrix products for the headline number")
     ap.add_argument("--train", action="store_true",
@@ -239,6 +262,32 @@ def main() -> None:
     prof = sc.profile_end()
     barrier()
 
+    # the other arithmetic modes on the same resident inputs (rank 0, two steps each): reported
+    # beside the headline, never as `value`
+    variants = {}
+    if rank == 0 and not args.no_variants:
+        for mode in ("f32", "f16x3", "f16", "bf16"):
+            if mode == args.precision:
+                continue
+            sc.set_precision(mode)
+            step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            step()
+            step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / 2
+            sc.profile_begin()
+            step()
+            vp = sc.profile_end()
+            torch.cuda.synchronize()
+            v_ms, v_launches = vp["branch51"]
+            v_tf = n * FLOPS_BRANCH[51] / (v_ms * 1e-3) / 1e12 if v_ms > 0 else 0.0
+            variants[mode] = {"sites_per_s_one_gpu": n / dt, "branch51_avg_launch_ms": v_ms / max(v_launches, 1),
+                              "branch51_tflops_algorithmic": v_tf, "branch51_frac_of_mfma_peak": v_tf / PEAK_MFMA[mode]}
+        sc.set_precision(args.precision)
+    barrier()
+
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = world * n * args.steps / elapsed
@@ -254,9 +303,11 @@ def main() -> None:
             "data": "synthetic (device-generated sites, seeded synthetic weights)",
             "config": {"workload": "config 3: 1M synthetic sites (windows 21/33/51 + ESM-2 1280 + 8 struct), fp32, 1 MI355X",
                        "sites_per_gpu": n, "parallelism": f"dp{world} (sites sharded, no collective)"},
-            "roofline": {"bound": "mfma", "kernel": "branch_kernel<51>", "achieved": achieved,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": KERNEL_NAME[args.precision], "achieved": achieved,
+                         "peak": PEAK_MFMA[args.precision], "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_MFMA[args.precision],
+                         "traffic": measured_traffic(args.precision, sites_per_launch),
+                         "traffic_source": "profiles/r1_pmc_traffic.json (offline rocprofv3 --pmc passes of this command)",
                          "avg_launch_ms": avg_s * 1e3, "sites_per_launch": sites_per_launch,
                          "flops_per_site": FLOPS_BRANCH[51]},
             "whole_path": {"tflops": value / world * FLOPS_PER_SITE / 1e12,
@@ -266,6 +317,8 @@ def main() -> None:
             "kernel_ms_per_step": {k: round(v[0], 3) for k, v in prof.items()},
             "kernel_ms_total": round(total_kernel_ms, 3),
         }
+        if variants:
+            line["variants"] = variants
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(weights)
         print(json.dumps(line))
