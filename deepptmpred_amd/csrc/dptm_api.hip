@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dptm.h"
@@ -164,6 +165,16 @@ struct dptm_handle {
     float* s_table = nullptr;
     int64_t s_table_cap = 0;
     int32_t* s_pos = nullptr;
+    // second staging slot, copy stream and events of the pipelined host-buffer entry point (dptm_score)
+    float* s2_strct = nullptr;
+    float* s2_esm = nullptr;
+    float* s2_out = nullptr;
+    uint8_t* s2_tok[3] = {nullptr, nullptr, nullptr};
+    float* pin_out[2] = {nullptr, nullptr};     // pinned host copies of a chunk's probabilities
+    uint8_t* pin_in[2] = {nullptr, nullptr};    // pinned host copies of a chunk's inputs (esm | struct | tok21 | tok33 | tok51)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copied[2] = {nullptr, nullptr};
+    hipEvent_t ev_scored[2] = {nullptr, nullptr};
     bool prof_armed = false;
     std::vector<ProfRec> prof;
 };
@@ -393,6 +404,53 @@ int ensure_host_staging(dptm_handle* h) {
     return DPTM_OK;
 }
 
+// layout of one pinned input slot
+constexpr size_t kPinEsm = 0;
+constexpr size_t kPinStruct = kPinEsm + (size_t)kChunkSites * kEsm * sizeof(float);
+constexpr size_t kPinTok21 = kPinStruct + (size_t)kChunkSites * kStruct * sizeof(float);
+constexpr size_t kPinTok33 = kPinTok21 + (size_t)kChunkSites * 21;
+constexpr size_t kPinTok51 = kPinTok33 + (size_t)kChunkSites * 33;
+constexpr size_t kPinInBytes = kPinTok51 + (size_t)kChunkSites * 51;
+
+// memcpy split over a few threads: one core moves ~10 GB/s, PCIe takes 50+
+void parallel_copy(void* dst, const void* src, size_t bytes) {
+    constexpr size_t kMinPerThread = 8u << 20;
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = std::min<size_t>(std::min<unsigned>(hw ? hw : 1u, 6u), bytes / kMinPerThread);
+    if (nt <= 1) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < nt; ++t) {
+        const size_t off = t * per;
+        if (off >= bytes) break;
+        const size_t len = std::min(per, bytes - off);
+        pool.emplace_back([=] { std::memcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, len); });
+    }
+    std::memcpy(dst, src, std::min(per, bytes));
+    for (auto& th : pool) th.join();
+}
+
+int ensure_pipeline(dptm_handle* h) {
+    if (h->ev_scored[1]) return DPTM_OK;
+    for (int b = 0; b < 3; ++b) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->s2_tok[b]), kChunkSites * kWin[b]));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->s2_strct), kChunkSites * kStruct * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->s2_esm), kChunkSites * (size_t)kEsm * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->s2_out), kChunkSites * 2 * sizeof(float)));
+    for (int s = 0; s < 2; ++s) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin_out[s]), kChunkSites * 2 * sizeof(float), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->pin_in[s]), kPinInBytes, hipHostMallocDefault));
+    }
+    HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    for (int s = 0; s < 2; ++s) {
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_copied[s], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_scored[s], hipEventDisableTiming));
+    }
+    return DPTM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -418,6 +476,17 @@ void dptm_destroy(dptm_handle* h) {
             if (h->d_branch_half[b][kind]) (void)hipFree(h->d_branch_half[b][kind]);
         if (h->d_tok[b]) (void)hipFree(h->d_tok[b]);
         if (h->s_tok[b]) (void)hipFree(h->s_tok[b]);
+        if (h->s2_tok[b]) (void)hipFree(h->s2_tok[b]);
+    }
+    if (h->copy_stream) {
+        (void)hipStreamSynchronize(h->copy_stream);
+        (void)hipStreamDestroy(h->copy_stream);
+    }
+    for (int s = 0; s < 2; ++s) {
+        if (h->ev_copied[s]) (void)hipEventDestroy(h->ev_copied[s]);
+        if (h->ev_scored[s]) (void)hipEventDestroy(h->ev_scored[s]);
+        if (h->pin_out[s]) (void)hipHostFree(h->pin_out[s]);
+        if (h->pin_in[s]) (void)hipHostFree(h->pin_in[s]);
     }
     free_dense(h->strct);
     free_dense(h->esm1);
@@ -426,7 +495,7 @@ void dptm_destroy(dptm_handle* h) {
     free_dense(h->t2);
     free_dense(h->head);
     void* bufs[] = {h->d_concat, h->d_h1, h->d_t1, h->d_t2, h->d_zero_row, h->d_esm_row, h->s_strct,
-                    h->s_esm, h->s_out, h->s_codes, h->s_table, h->s_pos};
+                    h->s_esm, h->s_out, h->s_codes, h->s_table, h->s_pos, h->s2_strct, h->s2_esm, h->s2_out};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -594,19 +663,48 @@ int dptm_score(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const
     HIP_TRY(hipSetDevice(h->device));
     int rc = ensure_host_staging(h);
     if (rc) return rc;
+    if ((rc = ensure_pipeline(h))) return rc;
+    // Two staging slots.  Per chunk: the host gathers the caller's (pageable) rows into a pinned block with a few
+    // threads, the copy stream moves that block over PCIe, the handle's stream scores it.  The gather of chunk i+1
+    // and its transfer run while chunk i is being scored; probabilities come back through pinned memory.
     const uint8_t* tk[3] = {tok21, tok33, tok51};
-    for (int64_t c0 = 0; c0 < n; c0 += kChunkSites) {
+    const size_t pin_tok[3] = {kPinTok21, kPinTok33, kPinTok51};
+    uint8_t* const* s_tok[2] = {h->s_tok, h->s2_tok};
+    float* const s_strct[2] = {h->s_strct, h->s2_strct};
+    float* const s_esm[2] = {h->s_esm, h->s2_esm};
+    float* const s_out[2] = {h->s_out, h->s2_out};
+    auto retire = [&](int slot, int64_t c0, int64_t m) -> int {
+        HIP_TRY(hipEventSynchronize(h->ev_scored[slot]));
+        std::memcpy(out + c0 * 2, h->pin_out[slot], (size_t)m * 2 * sizeof(float));
+        return DPTM_OK;
+    };
+    int64_t prev_c0 = 0, prev_m = 0;
+    int64_t i = 0;
+    for (int64_t c0 = 0; c0 < n; c0 += kChunkSites, ++i) {
         const int64_t m = n - c0 < kChunkSites ? n - c0 : kChunkSites;
+        const int slot = (int)(i & 1);
+        uint8_t* pin = h->pin_in[slot];
+        if (i >= 2) HIP_TRY(hipEventSynchronize(h->ev_copied[slot]));   // the pinned block has crossed PCIe
+        parallel_copy(pin + kPinEsm, esm + c0 * (int64_t)kEsm, (size_t)m * kEsm * sizeof(float));
+        std::memcpy(pin + kPinStruct, strct + c0 * kStruct, (size_t)m * kStruct * sizeof(float));
+        for (int b = 0; b < 3; ++b) std::memcpy(pin + pin_tok[b], tk[b] + c0 * kWin[b], (size_t)m * kWin[b]);
+        if (i >= 2) HIP_TRY(hipStreamWaitEvent(h->copy_stream, h->ev_scored[slot], 0));   // device slot free again
+        HIP_TRY(hipMemcpyAsync(s_esm[slot], pin + kPinEsm, (size_t)m * kEsm * sizeof(float), hipMemcpyHostToDevice, h->copy_stream));
+        HIP_TRY(hipMemcpyAsync(s_strct[slot], pin + kPinStruct, (size_t)m * kStruct * sizeof(float), hipMemcpyHostToDevice, h->copy_stream));
         for (int b = 0; b < 3; ++b)
-            HIP_TRY(hipMemcpyAsync(h->s_tok[b], tk[b] + c0 * kWin[b], m * kWin[b], hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(h->s_strct, strct + c0 * kStruct, m * kStruct * sizeof(float), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(h->s_esm, esm + c0 * (int64_t)kEsm, m * (size_t)kEsm * sizeof(float), hipMemcpyHostToDevice, h->stream));
-        const uint8_t* tok[3] = {h->s_tok[0], h->s_tok[1], h->s_tok[2]};
-        rc = score_chunk(h, tok, h->s_strct, h->s_esm, kEsm, nullptr, m, h->s_out, h->stream);
+            HIP_TRY(hipMemcpyAsync(s_tok[slot][b], pin + pin_tok[b], (size_t)m * kWin[b], hipMemcpyHostToDevice, h->copy_stream));
+        HIP_TRY(hipEventRecord(h->ev_copied[slot], h->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_copied[slot], 0));
+        const uint8_t* tok[3] = {s_tok[slot][0], s_tok[slot][1], s_tok[slot][2]};
+        rc = score_chunk(h, tok, s_strct[slot], s_esm[slot], kEsm, nullptr, m, s_out[slot], h->stream);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(out + c0 * 2, h->s_out, m * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipMemcpyAsync(h->pin_out[slot], s_out[slot], m * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipEventRecord(h->ev_scored[slot], h->stream));
+        if (i >= 1 && (rc = retire(slot ^ 1, prev_c0, prev_m))) return rc;
+        prev_c0 = c0;
+        prev_m = m;
     }
+    if ((rc = retire((int)((i - 1) & 1), prev_c0, prev_m))) return rc;
     return DPTM_OK;
 }
 
