@@ -4,10 +4,11 @@ call and the result table.  Same class and method names as the reference
 563-612 ``PTMPredictor``), so a script written against them keeps working; the model
 call goes to the MI355X library.
 
-Not built here: PyRosetta structure features (predict.py:172-321) -- a licensed
-third-party dependency.  Structure rows are an INPUT: pass ``struct_features`` or a
-``struct_calculator`` object with ``calculate_features(position) -> 8 floats``; without
-either, every site gets the reference's default row (predict.py:524-526).
+Structure rows (predict.py:172-321, PyRosetta in the reference) come from
+``deepptmpred_amd.structure.StructureCalculator`` when a PDB path is given, from a
+caller-supplied ``struct_features`` array or ``struct_calculator`` object
+(``calculate_features(position) -> 8 floats``) otherwise; with none of them every site gets
+the reference's default row (predict.py:524-526).
 """
 from __future__ import annotations
 
@@ -99,6 +100,12 @@ class PTMPredictDataLoader:
         self.config = config
         self.rosetta_calc = struct_calculator
 
+    def init_pyrosetta(self, pdb_path):
+        """predict.py:442-445 (name kept): lazily builds the structure calculator for a PDB file."""
+        if self.rosetta_calc is None:
+            from .structure import StructureCalculator
+            self.rosetta_calc = StructureCalculator(pdb_path)
+
     def load_custom_esm(self, protein_id: str):
         path = os.path.join(self.config.custom_esm_dir, f"{protein_id}_full_esm.npz")
         if not os.path.exists(path):
@@ -111,6 +118,8 @@ class PTMPredictDataLoader:
     def prepare_protein_data(self, protein_id, protein_sequence, positions=None, pdb_path=None):
         if positions is None:
             positions = [i + 1 for i, aa in enumerate(protein_sequence) if aa in self.config.target_aa]
+        if pdb_path:
+            self.init_pyrosetta(pdb_path)
         esm = self._prepare_esm_features(protein_id, protein_sequence, positions)
         st = self._generate_structural_features(positions)
         x_seq = [self._encode_sequences(self._get_sequence_windows(protein_sequence, positions, w))
@@ -174,6 +183,8 @@ class PTMPredictor:
             positions = [i + 1 for i, aa in enumerate(protein_sequence) if aa in self.config.target_aa]
         positions = list(positions)
         if struct_features is None:
+            if pdb_path:
+                self.data_loader.init_pyrosetta(pdb_path)
             struct_features = self.data_loader._generate_structural_features(positions)
         if fused and hasattr(self.model, "predict_protein"):
             # windows and ESM rows assembled on the GPU (same indexing as predict.py:487-501, 529-560)

@@ -73,6 +73,44 @@ def proteins():
     print({k: {t: v["n"] for t, v in m["sets"].items()} for k, m in meta.items()})
 
 
+def structure():
+    """Structure-feature fixtures from the reference's shipped AlphaFold model of AKT1
+    (data/AF-P31749-F1-model_v4.pdb, a data file): the ATOM records of residues 1..60 as a small
+    PDB, the brute-force oracle's SASA / torsions for it, and for the whole file the B-factor
+    list, the oracle's torsions and the numbers predict.ipynb prints (480 residues, 3919
+    B-factors, average plDDT 82.95)."""
+    from deepptmpred_amd import structure as S
+    from oracle import structure_oracle as SO
+    src = os.path.join(REF, "data", "AF-P31749-F1-model_v4.pdb")
+    head = os.path.join(HERE, "akt1_head60.pdb")
+    with open(src) as fin, open(head, "w") as fout:
+        for line in fin:
+            if line.startswith("ATOM") and int(line[22:26]) <= 60:
+                fout.write(line)
+        fout.write("END\n")
+    atoms = SO.read_atoms(head)
+    xyz = np.array([a[4] for a in atoms])
+    radii = np.array([S._atom_radius(a[1], a[0], a[6]) for a in atoms])
+    per_atom = SO.sasa_per_atom(xyz, radii, S.sphere_points(S.N_SPHERE_POINTS), S.PROBE_RADIUS)
+    res_of_atom = []
+    last, idx = None, 0
+    for a in atoms:
+        if (a[2], a[3]) != last:
+            idx += 1
+            last = (a[2], a[3])
+        res_of_atom.append(idx)
+    sasa_res = np.bincount(np.array(res_of_atom), weights=per_atom, minlength=61)
+    phi_h, psi_h = SO.torsions(atoms)
+    full = SO.read_atoms(src)
+    phi_f, psi_f = SO.torsions(full)
+    bf = np.array([a[5] for a in full])
+    np.savez_compressed(os.path.join(HERE, "structure_akt1.npz"), head_sasa_per_residue=sasa_res,
+                        head_phi=np.array(phi_h), head_psi=np.array(psi_h), full_phi=np.array(phi_f),
+                        full_psi=np.array(psi_f), full_bfactors=bf)
+    print("structure:", len(atoms), "atoms in head60;", len(full), "atoms,", len(phi_f) - 1, "residues, mean B", bf.mean())
+
+
 if __name__ == "__main__":
     synthetic()
     proteins()
+    structure()
