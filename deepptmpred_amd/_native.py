@@ -282,6 +282,7 @@ class Trainer:
         self._lib = load_library()
         self._h = C.c_void_p()
         self.spec = spec
+        self.max_batch = int(max_batch)
         self.n_canonical = int(np.asarray(blob).size)
         blob = np.ascontiguousarray(blob, dtype=np.float32)
         cs = DptmSpec.from_spec(spec)

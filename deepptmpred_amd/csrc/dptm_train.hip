@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -123,6 +124,23 @@ struct dptm_trainer {
     float *dconcat, *d512a, *d512b, *d256a, *d256b, *d128;
     int64_t step = 0;
     int64_t last_n = 0;
+    unsigned* d_step = nullptr;           // per-step scalars (StepParam)
+    // captured graph of one forward_backward: replayed while the call's shape, buffers and options repeat
+    struct GraphKey {
+        int64_t n = -1;
+        const void* ptr[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        float rate[4] = {0, 0, 0, 0};
+        float l2 = 0, l2_scale = 0;
+        hipStream_t st = nullptr;
+        bool operator==(const GraphKey& o) const {
+            return n == o.n && std::memcmp(ptr, o.ptr, sizeof ptr) == 0 && std::memcmp(rate, o.rate, sizeof rate) == 0 &&
+                   l2 == o.l2 && l2_scale == o.l2_scale && st == o.st;
+        }
+    };
+    GraphKey gkey;
+    int gkey_hits = 0;                    // consecutive eager calls with gkey
+    hipGraphExec_t gexec = nullptr;
+    bool use_graph = true;
 };
 
 namespace {
@@ -232,7 +250,7 @@ int conv_bwd(const Ctx& c, const float* x, const float* dout, int kid, int bid, 
 
 struct Rates { float embed, conv, tb, dense; };
 
-int branch_fwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, unsigned seed, const Rates& rt) {
+int branch_fwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigned* seed, const Rates& rt) {
     dptm_trainer* t = c.t;
     BranchAct& a = t->ba[b];
     const BranchP& p = t->pm.br[b];
@@ -272,7 +290,7 @@ int branch_fwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, unsigned seed
 }
 
 // dpool = d(concat)[:, b*64 .. +64]  ->  all parameter gradients of branch b
-int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, unsigned seed, const Rates& rt) {
+int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigned* seed, const Rates& rt) {
     dptm_trainer* t = c.t;
     BranchAct& a = t->ba[b];
     const BranchP& p = t->pm.br[b];
@@ -339,7 +357,9 @@ void dptm_trainer_destroy(dptm_trainer* t) {
     if (!t) return;
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
-    void* bufs[] = {t->W, t->G, t->M, t->V, t->trainable, t->arena.base};
+    (void)hipDeviceSynchronize();
+    if (t->gexec) (void)hipGraphExecDestroy(t->gexec);
+    void* bufs[] = {t->W, t->G, t->M, t->V, t->trainable, t->arena.base, t->d_step};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (t->stream) (void)hipStreamDestroy(t->stream);
@@ -372,8 +392,10 @@ int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spe
     const size_t pb = (size_t)t->pm.total * sizeof(float);
     if (hipMalloc((void**)&t->W, pb) != hipSuccess || hipMalloc((void**)&t->G, pb) != hipSuccess ||
         hipMalloc((void**)&t->M, pb) != hipSuccess || hipMalloc((void**)&t->V, pb) != hipSuccess ||
-        hipMalloc((void**)&t->trainable, (size_t)t->pm.total) != hipSuccess)
+        hipMalloc((void**)&t->trainable, (size_t)t->pm.total) != hipSuccess ||
+        hipMalloc((void**)&t->d_step, kStepParams * sizeof(unsigned)) != hipSuccess)
         return bail(DPTM_ENOMEM, "dptm_trainer_create: parameter buffers");
+    if (const char* env = std::getenv("DPTM_TRAIN_GRAPH")) t->use_graph = std::strcmp(env, "0") != 0;
     std::vector<float> host((size_t)t->pm.total, 0.0f);
     std::vector<uint8_t> tr((size_t)t->pm.total, 0);
     const float* src = static_cast<const float*>(weights);
@@ -406,19 +428,15 @@ int dptm_trainer_grad_buffer(dptm_trainer* t, float** dev_ptr, int64_t* count) {
     return DPTM_OK;
 }
 
-// Forward in training mode + loss + backward for one local batch (device pointers).
-int dptm_trainer_forward_backward(dptm_trainer* t, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
-                                  const float* strct, const float* esm, const int32_t* labels, int64_t n,
-                                  const dptm_train_opts* o, float* loss_out, void* stream) {
-    if (!t || !o) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward: NULL argument");
-    if (n < 1 || n > t->max_batch) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward: batch size outside 1..max_batch");
-    if (!tok21 || !tok33 || !tok51 || !strct || !esm || !labels) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward: NULL buffer");
-    T_TRY(hipSetDevice(t->device));
-    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : t->stream;
+// Enqueues forward (training mode) + loss + backward of one local batch on `st`.  No host synchronisation, no
+// allocation: the sequence can be captured into a graph.  Per-step scalars come from t->d_step.
+static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
+                                    const float* strct, const float* esm, const int32_t* labels, int64_t n,
+                                    const dptm_train_opts* o, hipStream_t st) {
     Ctx c{t, st, t->W, t->G};
     const PMap& pm = t->pm;
     const Rates rt{o->rate_embed, o->rate_conv, o->rate_tb, o->rate_dense};
-    const unsigned seed = o->seed;
+    const unsigned* seed = t->d_step;
     const uint8_t* tok[3] = {tok21, tok33, tok51};
     const int64_t B = n;
     int rc;
@@ -452,9 +470,7 @@ int dptm_trainer_forward_backward(dptm_trainer* t, const uint8_t* tok21, const u
     T_TRY(t_swish_fwd(t->t2a, t->t2y, B * 256, st));
     if ((rc = bn_train_fwd(c, t->t2y, t->t2z, 256, 0, B, 256, pm.t2.bn, t->t2mi))) return rc;
     // ---------------- head, loss and its gradient (trainer.py:36-54)
-    const float ng = o->n_global > 0 ? (float)o->n_global : (float)B;
-    float npos = (float)o->n_pos_global;
-    T_TRY(t_head_loss(t->t2z, c.w(pm.head.k), c.w(pm.head.b), labels, B, ng, npos, t->proba, t->d_loss, t->d256a,
+    T_TRY(t_head_loss(t->t2z, c.w(pm.head.k), c.w(pm.head.b), labels, B, t->d_step, t->proba, t->d_loss, t->d256a,
                       c.g(pm.head.k), c.g(pm.head.b), st));
     // ---------------- backward, per-site layers
     // trunk 2: BN -> swish -> dense
@@ -490,6 +506,67 @@ int dptm_trainer_forward_backward(dptm_trainer* t, const uint8_t* tok21, const u
     if (o->l2 > 0.f)
         for (const Tn& x : pm.t)
             if (x.l2) T_TRY(t_l2(t->W + x.off, t->G + x.off, x.size, o->l2 * o->l2_scale, t->d_loss, st));
+    return DPTM_OK;
+}
+
+// Forward in training mode + loss + backward for one local batch (device pointers).  The launch sequence
+// (about 300 small kernels) is captured into a graph the second time a call repeats the previous call's
+// batch size, buffers, dropout rates, l2 and stream, and replayed from then on; DPTM_TRAIN_GRAPH=0 disables it.
+int dptm_trainer_forward_backward(dptm_trainer* t, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
+                                  const float* strct, const float* esm, const int32_t* labels, int64_t n,
+                                  const dptm_train_opts* o, float* loss_out, void* stream) {
+    if (!t || !o) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward: NULL argument");
+    if (n < 1 || n > t->max_batch) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward: batch size outside 1..max_batch");
+    if (!tok21 || !tok33 || !tok51 || !strct || !esm || !labels) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward: NULL buffer");
+    T_TRY(hipSetDevice(t->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : t->stream;
+    const float ng = o->n_global > 0 ? (float)o->n_global : (float)n;
+    T_TRY(t_set_step(t->d_step, o->seed, ng, (float)o->n_pos_global, st));
+    dptm_trainer::GraphKey key;
+    key.n = n;
+    const void* ptrs[6] = {tok21, tok33, tok51, strct, esm, labels};
+    std::memcpy(key.ptr, ptrs, sizeof ptrs);
+    const float rates[4] = {o->rate_embed, o->rate_conv, o->rate_tb, o->rate_dense};
+    std::memcpy(key.rate, rates, sizeof rates);
+    key.l2 = o->l2;
+    key.l2_scale = o->l2_scale;
+    key.st = st;
+    int rc = DPTM_OK;
+    if (t->use_graph && t->gexec && key == t->gkey) {
+        T_TRY(hipGraphLaunch(t->gexec, st));
+    } else {
+        if (!(key == t->gkey)) {
+            if (t->gexec) {
+                (void)hipGraphExecDestroy(t->gexec);
+                t->gexec = nullptr;
+            }
+            t->gkey = key;
+            t->gkey_hits = 0;
+        }
+        const bool capture = t->use_graph && t->gkey_hits >= 1;   // the first call of a configuration runs eagerly
+        t->gkey_hits += 1;
+        if (capture) {
+            T_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            rc = enqueue_forward_backward(t, tok21, tok33, tok51, strct, esm, labels, n, o, st);
+            hipGraph_t graph = nullptr;
+            const hipError_t e = hipStreamEndCapture(st, &graph);
+            if (rc) {
+                if (graph) (void)hipGraphDestroy(graph);
+                return rc;
+            }
+            if (e != hipSuccess || !graph) return tfail(DPTM_EHIP, "dptm_trainer_forward_backward: stream capture failed");
+            const hipError_t ei = hipGraphInstantiate(&t->gexec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ei != hipSuccess) {
+                t->gexec = nullptr;
+                return tfail(DPTM_EHIP, "dptm_trainer_forward_backward: graph instantiation failed");
+            }
+            T_TRY(hipGraphLaunch(t->gexec, st));
+        } else {
+            rc = enqueue_forward_backward(t, tok21, tok33, tok51, strct, esm, labels, n, o, st);
+            if (rc) return rc;
+        }
+    }
     t->last_n = n;
     if (loss_out) {
         T_TRY(hipMemcpyAsync(loss_out, t->d_loss, sizeof(float), hipMemcpyDeviceToHost, st));

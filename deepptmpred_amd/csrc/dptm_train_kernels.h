@@ -48,7 +48,12 @@ hipError_t t_swish_bwd(const float* a, const float* dy, float* da, int64_t n, hi
 hipError_t t_add(float* dst, const float* src, int64_t n, hipStream_t st);
 hipError_t t_copy_cols(float* dst, int64_t ldd, int dc, const float* src, int64_t lds_, int sc, int64_t rows,
                        int cols, bool add, hipStream_t st);
-hipError_t t_dropout(float* x, int64_t rows, int cols, int64_t ld, int wlen_spatial, unsigned seed, unsigned stream,
+// Scalars that change every step live in a small device array so that a captured graph of the step can be
+// replayed unchanged: [kStepSeed] dropout seed, [kStepNGlobal] / [kStepNPosGlobal] float bits of the global
+// batch size and positive count of the loss weights.  t_set_step writes them (stream-ordered).
+enum StepParam { kStepSeed = 0, kStepNGlobal = 1, kStepNPosGlobal = 2, kStepParams = 4 };
+hipError_t t_set_step(unsigned* step_params, unsigned seed, float n_global, float n_pos_global, hipStream_t st);
+hipError_t t_dropout(float* x, int64_t rows, int cols, int64_t ld, int wlen_spatial, const unsigned* step_params, unsigned stream,
                      float rate, hipStream_t st);
 hipError_t t_embed_fwd(const uint8_t* tok, const float* E, const float* P, float* x, int64_t rows, int wlen, hipStream_t st);
 hipError_t t_embed_bwd(const uint8_t* tok, const float* dx, float* dE, float* dP, int64_t rows, int wlen, hipStream_t st);
@@ -70,8 +75,8 @@ hipError_t t_pool_fwd(const float* x, const float* w, const float* bias, float* 
                       float* alpha_save, int64_t samples, int wlen, hipStream_t st);
 hipError_t t_pool_bwd(const float* x, const float* w, const float* dout, int64_t ldd, int col_off, const float* a_save,
                       const float* alpha_save, float* dx, float* dw, float* db, int64_t samples, int wlen, hipStream_t st);
-hipError_t t_head_loss(const float* x, const float* W, const float* bias, const int32_t* labels, int64_t n, float n_global,
-                       float n_pos_global, float* proba, float* loss, float* dx, float* dW, float* db, hipStream_t st);
+hipError_t t_head_loss(const float* x, const float* W, const float* bias, const int32_t* labels, int64_t n,
+                       const unsigned* step_params, float* proba, float* loss, float* dx, float* dW, float* db, hipStream_t st);
 hipError_t t_l2(const float* w, float* g, int64_t n, float lambda, float* loss, hipStream_t st);
 hipError_t t_adamw(float* w, const float* g, float* m, float* v, const uint8_t* trainable, float stat_scale, int64_t n,
                    float lr_t, float wd, float b1, float b2, float eps, float gscale, hipStream_t st);

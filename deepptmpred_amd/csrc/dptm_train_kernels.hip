@@ -65,24 +65,35 @@ __global__ __launch_bounds__(256) void tgemm_kernel(GemmArgs p) {
             for (int e = 0; e < 4; ++e)
                 acc[t][4 * g + e] = p.bias ? p.bias[c0 + 32 * t + 8 * g + 4 * h + e] : 0.f;
     const int k8 = p.k >> 3;
-    for (int u = 0; u < k8; ++u) {
-        f32x4 b = *reinterpret_cast<const f32x4*>(xin + 8 * u);
-        if (!ok) b = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 a[2];
+    // the contraction is walked in blocks of 64 inputs whose operands are all requested before the first
+    // MFMA of the block: these layers are a few steps deep, so the loads' latency is the cost to hide
+    for (int ub = 0; ub < k8; ub += 8) {
+        f32x4 b[8], a[8][2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int c = c0 + 32 * t + j;
-            if (NT) {
-                a[t] = *reinterpret_cast<const f32x4*>(p.w + (int64_t)c * p.ldw + 8 * u + 4 * h);
-            } else {
+        for (int v = 0; v < 8; ++v) {
+            const int u = ub + v;
+            b[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+            a[v][0] = a[v][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (u < k8) {
+                if (ok) b[v] = *reinterpret_cast<const f32x4*>(xin + 8 * u);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a[t][e] = p.w[(int64_t)(8 * u + 4 * h + e) * p.ldw + c];
+                for (int t = 0; t < 2; ++t) {
+                    const int c = c0 + 32 * t + j;
+                    if (NT) {
+                        a[v][t] = *reinterpret_cast<const f32x4*>(p.w + (int64_t)c * p.ldw + 8 * u + 4 * h);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a[v][t][e] = p.w[(int64_t)(8 * u + 4 * h + e) * p.ldw + c];
+                    }
+                }
             }
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int v = 0; v < 8; ++v)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) mfma2(acc[t], a[t][e], b[e]);
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) mfma2(acc[t], a[v][t][e], b[v][e]);
     }
     if (r >= p.m) return;
     float* orow = p.out + r * p.ldo + p.col_off + c0 + 4 * h;
@@ -110,15 +121,24 @@ __global__ __launch_bounds__(64) void tgemm_tn_kernel(GemmTnArgs p) {
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
     const bool kin = k0 + i < p.k;
-    for (int64_t rr = rs; rr < re; rr += 2) {   // half-wave h takes row rr+h of every pair
-        const int64_t r = rr + h;
-        float a = 0.f, b = 0.f;
-        if (r < re) {
-            b = p.dy[r * p.ldy + p.dy_col_off + n0 + i];
-            if (kin && row_ok(r, p.shift, p.m, p.wlen)) a = p.x[(r + p.shift) * p.ldx + p.x_col_off + k0 + i];
+    // half-wave h takes row rr+h of every pair; four pairs per trip so that eight loads are in flight
+    for (int64_t rr = rs; rr < re; rr += 8) {
+        float a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t r = rr + 2 * q + h;
+            a[q] = 0.f;
+            b[q] = 0.f;
+            if (r < re) {
+                b[q] = p.dy[r * p.ldy + p.dy_col_off + n0 + i];
+                if (kin && row_ok(r, p.shift, p.m, p.wlen)) a[q] = p.x[(r + p.shift) * p.ldx + p.x_col_off + k0 + i];
+            }
         }
-        mfma2(acc, a, b);
-        bsum += b;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mfma2(acc, a[q], b[q]);
+            bsum += b[q];
+        }
     }
     // D[row = k][col = n]: lane holds column n0+i, rows (reg&3) + 8*(reg>>2) + 4*h
 #pragma unroll
@@ -171,7 +191,8 @@ __global__ void copy_cols_kernel(float* __restrict__ dst, int64_t ldd, int dc, c
 // inverted dropout in place.  spatial: one mask value per (sample, channel) of a
 // [samples][wlen][cols] stack; otherwise per element.  ld = row stride, cols = row width.
 __global__ void dropout_kernel(float* __restrict__ x, int64_t rows, int cols, int64_t ld, int wlen_spatial,
-                               unsigned seed, unsigned stream, unsigned thr, float scale) {
+                               const unsigned* __restrict__ step_params, unsigned stream, unsigned thr, float scale) {
+    const unsigned seed = step_params[kStepSeed];
     const int64_t total = rows * cols;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / cols;
@@ -561,10 +582,12 @@ __global__ __launch_bounds__(64) void pool_bwd_kernel(const float* __restrict__ 
 // d(logits); then dW, db (atomics) and dx.  One wavefront per sample.
 __global__ __launch_bounds__(64) void head_loss_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                        const float* __restrict__ bias, const int32_t* __restrict__ labels,
-                                                       int64_t n, float n_global, float n_pos_global,
+                                                       int64_t n, const unsigned* __restrict__ step_params,
                                                        float* __restrict__ proba, float* __restrict__ loss,
                                                        float* __restrict__ dx, float* __restrict__ dW,
                                                        float* __restrict__ db) {
+    const float n_global = __uint_as_float(step_params[kStepNGlobal]);
+    const float n_pos_global = __uint_as_float(step_params[kStepNPosGlobal]);
     const int64_t s = blockIdx.x;
     const int lane = threadIdx.x;
     float l0 = 0.f, l1 = 0.f;
@@ -675,10 +698,13 @@ hipError_t t_gemm(const GemmArgs& a, bool nt, hipStream_t st) {
 hipError_t t_gemm_tn(GemmTnArgs a, hipStream_t st) {
     if (a.m == 0) return hipSuccess;
     if (a.n % 32 != 0) return hipErrorInvalidValue;
-    int64_t slabs = (a.m + 511) / 512;
-    if (slabs > 512) slabs = 512;
+    // enough row slabs that tiles x slabs fills the chip (~2048 wavefronts), but at least 64 rows each
+    const int64_t tiles = (int64_t)((a.k + 31) / 32) * (a.n / 32);
+    int64_t slabs = (2048 + tiles - 1) / tiles;
+    if (slabs > (a.m + 63) / 64) slabs = (a.m + 63) / 64;
+    if (slabs < 1) slabs = 1;
     a.rows_per_slab = (a.m + slabs - 1) / slabs;
-    a.rows_per_slab += a.rows_per_slab & 1;   // even: the two half-waves alternate rows
+    a.rows_per_slab = (a.rows_per_slab + 7) & ~(int64_t)7;   // multiple of 8: four row pairs per loop trip
     slabs = (a.m + a.rows_per_slab - 1) / a.rows_per_slab;
     dim3 grid((unsigned)((a.k + 31) / 32), (unsigned)(a.n / 32), (unsigned)slabs);
     hipLaunchKernelGGL(tgemm_tn_kernel, grid, dim3(64), 0, st, a);
@@ -702,12 +728,12 @@ hipError_t t_copy_cols(float* dst, int64_t ldd, int dc, const float* src, int64_
     if (rows) hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, st, dst, ldd, dc, src, lds_, sc, rows, cols, add ? 1 : 0);
     return hipGetLastError();
 }
-hipError_t t_dropout(float* x, int64_t rows, int cols, int64_t ld, int wlen_spatial, unsigned seed, unsigned stream,
+hipError_t t_dropout(float* x, int64_t rows, int cols, int64_t ld, int wlen_spatial, const unsigned* step_params, unsigned stream,
                      float rate, hipStream_t st) {
     if (rate <= 0.f || rows == 0) return hipSuccess;
     double t = (double)rate * 4294967296.0;
     const unsigned thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
-    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, st, x, rows, cols, ld, wlen_spatial, seed,
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, st, x, rows, cols, ld, wlen_spatial, step_params,
                        stream, thr, 1.0f / (1.0f - rate));
     return hipGetLastError();
 }
@@ -717,7 +743,9 @@ hipError_t t_embed_fwd(const uint8_t* tok, const float* E, const float* P, float
 }
 hipError_t t_embed_bwd(const uint8_t* tok, const float* dx, float* dE, float* dP, int64_t rows, int wlen, hipStream_t st) {
     if (rows == 0) return hipSuccess;
-    const int rpb = 2048;
+    int64_t rpb64 = rows / 1024;                     // ~1024 blocks for large batches, 64 rows each for small ones
+    if (rpb64 < 64) rpb64 = 64;
+    const int rpb = (int)rpb64;
     hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st, tok, dx, dE, dP, rows, wlen, rpb);
     return hipGetLastError();
 }
@@ -787,9 +815,20 @@ hipError_t t_pool_bwd(const float* x, const float* w, const float* dout, int64_t
     if (samples) hipLaunchKernelGGL(pool_bwd_kernel, dim3((unsigned)samples), dim3(64), 0, st, x, w, dout, ldd, col_off, a_save, alpha_save, dx, dw, db, wlen);
     return hipGetLastError();
 }
-hipError_t t_head_loss(const float* x, const float* W, const float* bias, const int32_t* labels, int64_t n, float n_global,
-                       float n_pos_global, float* proba, float* loss, float* dx, float* dW, float* db, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(head_loss_kernel, dim3((unsigned)n), dim3(64), 0, st, x, W, bias, labels, n, n_global, n_pos_global, proba, loss, dx, dW, db);
+hipError_t t_head_loss(const float* x, const float* W, const float* bias, const int32_t* labels, int64_t n,
+                       const unsigned* step_params, float* proba, float* loss, float* dx, float* dW, float* db, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(head_loss_kernel, dim3((unsigned)n), dim3(64), 0, st, x, W, bias, labels, n, step_params, proba, loss, dx, dW, db);
+    return hipGetLastError();
+}
+__global__ void set_step_kernel(unsigned* step_params, unsigned seed, float n_global, float n_pos_global) {
+    if (threadIdx.x == 0) {
+        step_params[kStepSeed] = seed;
+        step_params[kStepNGlobal] = __float_as_uint(n_global);
+        step_params[kStepNPosGlobal] = __float_as_uint(n_pos_global);
+    }
+}
+hipError_t t_set_step(unsigned* step_params, unsigned seed, float n_global, float n_pos_global, hipStream_t st) {
+    hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(64), 0, st, step_params, seed, n_global, n_pos_global);
     return hipGetLastError();
 }
 hipError_t t_l2(const float* w, float* g, int64_t n, float lambda, float* loss, hipStream_t st) {
