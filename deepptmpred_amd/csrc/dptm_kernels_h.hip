@@ -85,8 +85,15 @@ __device__ __forceinline__ Frag<MODE> load_w(const uint4* __restrict__ hi, const
 __device__ __forceinline__ float exp2_h(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_rcp_h(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float swish_h(float x) { return x * fast_rcp_h(1.0f + __expf(-x)); }
-__device__ __forceinline__ float xhalf_sum_h(float v) { return v + __shfl_xor(v, 32); }
-__device__ __forceinline__ float xhalf_max_h(float v) { return fmaxf(v, __shfl_xor(v, 32)); }
+// sum / max over the two half-wave lanes with the same j: v_permlane32_swap on two copies leaves (own, other)
+__device__ __forceinline__ float xhalf_sum_h(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xhalf_max_h(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 
 template <int NT>
 __device__ __forceinline__ void acc_bias(f32x16 (&acc)[NT], const f32x4* __restrict__ vec, int h, int groups_per_half) {
@@ -213,6 +220,8 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
     // bias / scale / LayerNorm vectors of the whole branch, copied once: a vector read costs the texture path
     // as much as a weight fragment, and there are more of them than weight fragments
     f32x4* vecs = reinterpret_cast<f32x4*>(lds_h + 2 * kRegionB + kTileRows * sizeof(float));
+    // one-hot "site of this key" operand fragments, [S + 1 sites][2 halves] x 16 B (site S = padding rows)
+    uint4* site_frag = reinterpret_cast<uint4*>(lds_h + 2 * kRegionB + kTileRows * sizeof(float) + kVecsF4 * 16);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -228,9 +237,6 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
     const int pos_l = row_ok ? row - site_l * W : 0;
     const bool tap0_ok = row_ok && pos_l > 0;
     const bool tap2_ok = row_ok && pos_l < W - 1;
-    // keys this lane's query may attend to: its own site, or only itself for a padding row
-    const int k_start = row_ok ? site_l * W : row;
-    const int k_len = row_ok ? W : 1;
     // aligned 32-key tiles this wavefront needs (wave-uniform)
     int b_lo, nb;
     {
@@ -246,17 +252,28 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
             nb = (min(klast, kTileRows - 1) >> 5) - b_lo + 1;
         }
     }
-    // per-tile validity masks (bit r <-> accumulator register r of the S^T tile), fixed for the kernel
-    unsigned kmask[MAXNB];
+    // Keys outside the query's own site are pushed out of the softmax by one extra MFMA per score tile:
+    // key operand = one-hot of the key's site over 16 "site" dimensions, query operand = 0 on the query's
+    // own site and -60000 elsewhere, so their product adds 0 or -60000 to the score (scores are O(10)).
+    // Padding rows form a site of their own.  LDS byte offset of the key fragment per tile:
+    int site_frag_off[MAXNB];
 #pragma unroll
     for (int bi = 0; bi < MAXNB; ++bi) {
-        unsigned m = 0;
+        const int krow = 32 * (b_lo + bi) + j;
+        const int ks = krow < rows_valid ? krow / W : S;
+        site_frag_off[bi] = (ks * 2 + h) * 16;
+    }
+    typename HP<MODE>::frag qsite;      // query-side operand, fixed for the kernel
+    {
+        const int qs = row_ok ? site_l : S;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int krow = 32 * (b_lo + bi) + (r & 3) + 8 * (r >> 2) + 4 * h;
-            m |= ((unsigned)(krow - k_start) < (unsigned)k_len ? 1u : 0u) << r;
-        }
-        kmask[bi] = bi < nb ? m : 0u;
+        for (int idx = 0; idx < 8; ++idx) qsite[idx] = (8 * h + idx == qs) ? (E)0.0f : (E)(-60000.0f);
+    }
+    if (tid < (S + 1) * 2) {
+        typename HP<MODE>::frag f;
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) f[idx] = (8 * (tid & 1) + idx == (tid >> 1)) ? (E)1.0f : (E)0.0f;
+        site_frag[tid] = as_u4<MODE>(f);
     }
 #ifdef ABL_H_NB
     nb = min(nb, ABL_H_NB);
@@ -424,7 +441,10 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
             for (int bi = 0; bi < MAXNB; ++bi) {
                 if (bi < nb) {
                     // S^T tile: rows = keys of tile b_lo+bi, columns = this wave's 32 queries
-                    f32x16 st = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    const typename HP<MODE>::frag ksite = as_frag<MODE>(
+                        *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(site_frag) + site_frag_off[bi]));
+                    f32x16 st = mfma16(ksite, qsite, zero);
                     mac<MODE>(st, kf, fq[hd]);
                     // operands of the next steps are fetched while the MFMA runs
                     const char* vp = regB + (32 * (hd >> 1) + j) * kVtRowB + ((b_lo + bi) * 4 + h) * 16;
@@ -436,13 +456,9 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
                         vf1.lo = as_frag<MODE>(*reinterpret_cast<const uint4*>(vp + kVtLoOff + 32));
                     }
                     if (bi + 1 < MAXNB && bi + 1 < nb) kf = load_frag<MODE>(regA, 32 * (b_lo + bi + 1) + j, hd, h);
-                    float tm = -3.0e38f;
+                    float tm = st[0];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float sv = (kmask[bi] >> r) & 1u ? st[r] : -3.0e38f;
-                        st[r] = sv;
-                        tm = fmaxf(tm, sv);
-                    }
+                    for (int r = 1; r < 16; ++r) tm = fmaxf(tm, st[r]);
                     const float mn = fmaxf(m, xhalf_max_h(tm));
                     const float alpha = exp2_h(m - mn);
                     m = mn;
@@ -701,7 +717,7 @@ hipError_t launch_dense_h(int mode, const DenseArgs& a, int epi, const void* whi
     }
 }
 
-static constexpr size_t kBranchLdsH = 2 * (size_t)kRegionB + kTileRows * sizeof(float) + kVecsF4 * 16;
+static constexpr size_t kBranchLdsH = 2 * (size_t)kRegionB + kTileRows * sizeof(float) + kVecsF4 * 16 + 13 * 2 * 16;
 
 template <int W, int MODE>
 static hipError_t launch_branch_h_t(const float* params, const void* whi, const void* wlo, const uint8_t* tok, int64_t n,
