@@ -14,9 +14,6 @@
 
 #include "dptm_layout.h"
 #include "dptm_kernels.h"
-#ifndef ABL_HEADS
-#define ABL_HEADS 2
-#endif
 
 namespace dptm {
 
@@ -332,7 +329,7 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
         // Keys are walked in three chunks of W/3 with a running maximum (the usual
         // rescaling form of softmax), which keeps only W/3 scores live per lane.
 #pragma unroll
-        for (int hd = 0; hd < ABL_HEADS; ++hd) {
+        for (int hd = 0; hd < 2; ++hd) {
             constexpr int CH = W / 3;
             static_assert(CH * 3 == W, "window sizes are multiples of 3");
             const float* kp = bufA + row_start * kLdsStride + 32 * h + 16 * hd;

@@ -275,9 +275,6 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
         for (int idx = 0; idx < 8; ++idx) f[idx] = (8 * (tid & 1) + idx == (tid >> 1)) ? (E)1.0f : (E)0.0f;
         site_frag[tid] = as_u4<MODE>(f);
     }
-#ifdef ABL_H_NB
-    nb = min(nb, ABL_H_NB);
-#endif
 
     for (int i = threadIdx.x; i < kVecsF4; i += 512) vecs[i] = P[vecs_source(i)];
     // ---- embedding + position embedding, this lane's row in the chain layout (model.py:157-158)
@@ -476,9 +473,6 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
                     mac<MODE>(ao, vf1, make_frag<MODE>(p[2], p[3]));
                 }
             }
-#ifdef ABL_H_NB
-            den += 1.0f;
-#endif
             const float rden = 1.0f / xhalf_sum_h(den);
             // rows of ao = features 32*(hd>>1) + 8g + 4h + e; this head owns g = 2*(hd&1), 2*(hd&1)+1
 #pragma unroll
@@ -521,11 +515,7 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
             for (int ks = 0; ks < 4; ++ks) fh[ks] = make_frag<MODE>(hres[2 * ks], hres[2 * ks + 1]);
             f32x16 acc_o[2];
             acc_bias<2>(acc_o, tv + kVB2 * kVec64, h, 8);
-#ifdef ABL_H_NOFFN
-            constexpr int NCH = 0;
-#else
             constexpr int NCH = 8 / HT;
-#endif
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 f32x16 acc_h[HT];
