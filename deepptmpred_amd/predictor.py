@@ -212,3 +212,30 @@ def run_protein(ptm_type: str, project_root: str, pdb_path: str, model_path: Opt
     path = os.path.join(out_dir, f"{pid}_{ptm_type}_predictions.csv")
     df.to_csv(path, index=False)
     return df, path
+
+
+def run_all_ptm_types(project_root: str, pdb_path: str, model_paths: Optional[dict] = None, out_dir: Optional[str] = None,
+                      ptm_types: Optional[Sequence[str]] = None, device: int = 0):
+    """The 17-type sweep of the notebook menu (predict.ipynb cell 5; type -> residues from predict.py:119-137)
+    for one protein: the sequence, the structure rows and the ESM table are prepared once, each PTM
+    type scores its own target residues with its own weight file.  Types whose weight file is missing
+    are skipped and reported.  Returns ``({ptm_type: DataFrame}, [skipped types])``."""
+    pid = extract_protein_id_from_pdb_path(pdb_path)
+    seq = extract_sequence_from_pdb(pdb_path, chain_id="A")
+    calc = None
+    results, skipped = {}, []
+    out_dir = out_dir or os.path.join(project_root, "results")
+    for ptm_type in (ptm_types or list(PTM_AA_MAP)):
+        cfg = PredictConfig(ptm_type, project_root, (model_paths or {}).get(ptm_type))
+        if not os.path.exists(cfg.model_path):
+            skipped.append(ptm_type)
+            continue
+        predictor = PTMPredictor(cfg, struct_calculator=calc, device=device)
+        positions = [i + 1 for i, aa in enumerate(seq) if aa in cfg.target_aa]
+        df = predictor.predict_ptm_sites(pid, seq, positions, pdb_path=pdb_path)
+        calc = predictor.data_loader.rosetta_calc          # structure features are per protein, not per type
+        predictor.model.close()
+        os.makedirs(out_dir, exist_ok=True)
+        df.to_csv(os.path.join(out_dir, f"{pid}_{ptm_type}_predictions.csv"), index=False)
+        results[ptm_type] = df
+    return results, skipped

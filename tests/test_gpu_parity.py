@@ -192,3 +192,31 @@ def test_predictor_table_on_gpu(model, weights, golden_dir, tmp_path):
     ref = oracle(weights, toks + [np.tile(O.DEFAULT_STRUCT_ROW, (80, 1)), esm])[:, 1]
     assert np.abs(a["probability"].to_numpy() - ref).max() < TOL
     assert set(a[a["position"].isin([202, 205, 231, 262, 356])]["residue"]) <= {"S", "T"}   # case.py:541
+
+
+def test_ptm_type_sweep_on_gpu(weights, golden_dir, tmp_path):
+    """The multi-type sweep over one structure file: each type scores its own residues with its own
+    weights; structure rows come from the PDB; missing weight files are reported, not fatal."""
+    import shutil
+    from deepptmpred_amd.predictor import run_all_ptm_types
+    from deepptmpred_amd.structure import StructureCalculator
+    root = str(tmp_path)
+    pdb = os.path.join(root, "AF-P31749-F1-model_v4.pdb")
+    shutil.copy(os.path.join(golden_dir, "akt1_head60.pdb"), pdb)
+    paths = {}
+    for seed, t in ((7, "phosphorylation"), (100, "ubiquitination")):
+        paths[t] = os.path.join(root, t + ".dptm")
+        spec.save_flat(paths[t], spec.synthetic_weights(seed))
+    res, skipped = run_all_ptm_types(root, pdb, paths, ptm_types=["phosphorylation", "ubiquitination", "acetylation"])
+    assert skipped == ["acetylation"] and set(res) == {"phosphorylation", "ubiquitination"}
+    seq = "".join(res["phosphorylation"]["residue"])
+    assert set(seq) <= {"S", "T"} and set(res["ubiquitination"]["residue"]) == {"K"}
+    assert os.path.exists(os.path.join(root, "results", "P31749_ubiquitination_predictions.csv"))
+    # same numbers as scoring by hand with the oracle (no ESM file -> zero rows, predict.py:498-500)
+    calc = StructureCalculator(pdb)
+    from deepptmpred_amd.predictor import extract_sequence_from_pdb
+    full = extract_sequence_from_pdb(pdb, "A")
+    pos = res["ubiquitination"]["position"].to_numpy()
+    toks = [O.encode_sequences(O.get_sequence_windows(full, list(pos), w)) for w in (21, 33, 51)]
+    ref = oracle(spec.synthetic_weights(100), toks + [calc.features(pos), np.zeros((len(pos), 1280))])[:, 1]
+    assert np.abs(res["ubiquitination"]["probability"].to_numpy() - ref).max() < TOL
