@@ -30,7 +30,7 @@ EXPORTS = (
     "dptm_set_precision", "dptm_trainer_create", "dptm_trainer_destroy", "dptm_trainer_forward_backward",
     "dptm_trainer_grad_buffer", "dptm_trainer_param_floats", "dptm_trainer_apply",
     "dptm_trainer_get_weights", "dptm_trainer_get_grads", "dptm_trainer_get_proba",
-    "dptm_trainer_last_error",
+    "dptm_trainer_last_error", "dptm_sasa", "dptm_sasa_last_error",
 )
 
 
@@ -158,6 +158,10 @@ def load_library() -> C.CDLL:
     lib.dptm_trainer_get_proba.argtypes = [vp, f32p, i64]
     lib.dptm_trainer_last_error.restype = C.c_char_p
     lib.dptm_trainer_last_error.argtypes = []
+    lib.dptm_sasa.restype = C.c_int
+    lib.dptm_sasa.argtypes = [vp, vp, i64, C.c_double, vp, C.c_int32, C.c_int32, vp]
+    lib.dptm_sasa_last_error.restype = C.c_char_p
+    lib.dptm_sasa_last_error.argtypes = []
     _lib = lib
     return lib
 
@@ -175,6 +179,22 @@ def _check(lib, rc: int, what: str) -> None:
 
 def _ptr(a: np.ndarray) -> C.c_void_p:
     return C.c_void_p(a.ctypes.data)
+
+
+def sasa(xyz: np.ndarray, radii: np.ndarray, probe: float, unit_points: np.ndarray, device: int = 0) -> np.ndarray:
+    """Per-atom solvent-accessible area on the GPU (``dptm_sasa``); float64 in, float64 out."""
+    lib = load_library()
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+    radii = np.ascontiguousarray(radii, dtype=np.float64)
+    unit_points = np.ascontiguousarray(unit_points, dtype=np.float64).reshape(-1, 3)
+    if len(radii) != len(xyz):
+        raise ValueError("sasa: xyz and radii differ in length")
+    out = np.zeros(len(xyz), dtype=np.float64)
+    rc = lib.dptm_sasa(_ptr(xyz), _ptr(radii), len(xyz), float(probe), _ptr(unit_points), len(unit_points), device, _ptr(out))
+    if rc != DPTM_OK:
+        msg = (lib.dptm_sasa_last_error() or b"").decode("utf-8", "replace")
+        raise (ValueError if rc == DPTM_EINVAL else RuntimeError)(msg)
+    return out
 
 
 class Scorer:

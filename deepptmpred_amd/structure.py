@@ -153,9 +153,18 @@ def backbone_torsions(atoms: PdbAtoms, max_peptide_bond: float = 2.0) -> Tuple[n
 
 
 def shrake_rupley(xyz: np.ndarray, radii: np.ndarray, probe: float = PROBE_RADIUS,
-                  n_points: int = N_SPHERE_POINTS) -> np.ndarray:
+                  n_points: int = N_SPHERE_POINTS, backend: str = "numpy", device: int = 0) -> np.ndarray:
     """Solvent-accessible area per atom (A^2): fraction of the n_points test points on the
-    sphere of radius r_i + probe that lie outside every neighbour's expanded sphere."""
+    sphere of radius r_i + probe that lie outside every neighbour's expanded sphere.
+
+    ``backend="hip"`` runs the same count on the GPU (``dptm_sasa`` in libdptm.so, fp64, same
+    operation order: bit-identical areas) and raises if the library or the GPU is missing;
+    ``"numpy"`` is the host implementation, the counterpart of the reference's host-side call."""
+    if backend == "hip":
+        from . import _native
+        return _native.sasa(xyz, radii, probe, sphere_points(n_points), device)
+    if backend != "numpy":
+        raise ValueError("backend must be 'numpy' or 'hip'")
     from scipy.spatial import cKDTree
     n = len(xyz)
     area = np.zeros(n)
@@ -187,7 +196,7 @@ def shrake_rupley(xyz: np.ndarray, radii: np.ndarray, probe: float = PROBE_RADIU
 class StructureCalculator:
     """Stand-in for ``PyRosettaCalculator`` (predict.py:172-321)."""
 
-    def __init__(self, pdb_path: Optional[str] = None, verbose: bool = False):
+    def __init__(self, pdb_path: Optional[str] = None, verbose: bool = False, sasa_backend: str = "numpy", device: int = 0):
         self.pose = None                    # the parsed atoms (``PdbAtoms``), None when no file was given
         self.plDDT_values: List[float] = []
         self.res_sasa: Dict[int, Tuple[float, float, float]] = {}
@@ -199,10 +208,13 @@ class StructureCalculator:
             raise FileNotFoundError(f"PDB file does not exist: {pdb_path}")     # predict.py:194-195
         atoms = PdbAtoms(pdb_path)
         self.pose = atoms
+        radii = np.array([_atom_radius(atoms.resnames[i], atoms.names[i], atoms.elements[i])
+                          for i in range(len(atoms.names))])
+        # the GPU backend fails loudly (missing library, no device); only the host computation gets the
+        # reference's "SASA failed -> zeros" treatment
+        gpu_area = shrake_rupley(atoms.xyz, radii, backend="hip", device=device) if sasa_backend == "hip" else None
         try:
-            radii = np.array([_atom_radius(atoms.resnames[i], atoms.names[i], atoms.elements[i])
-                              for i in range(len(atoms.names))])
-            per_atom = shrake_rupley(atoms.xyz, radii)
+            per_atom = gpu_area if gpu_area is not None else shrake_rupley(atoms.xyz, radii, backend=sasa_backend)
             per_res = np.bincount(atoms.residue_index, weights=per_atom, minlength=atoms.n_residues + 1)
             for r in range(1, atoms.n_residues + 1):
                 total = float(per_res[r])

@@ -140,9 +140,9 @@ enum {
 int dptm_profile_begin(dptm_handle* h);
 int dptm_profile_end(dptm_handle* h, float* ms, int64_t* launches);
 
-/* Arithmetic of the matrix products in the fused sequence branches (the per-site dense
- * layers always run in fp32).  Everything else -- normalisation, softmax, activations,
- * accumulation -- is fp32 in every mode.  No counterpart in the reference (Keras runs the
+/* Arithmetic of the matrix products in the fused sequence branches and in the ESM / trunk dense
+ * layers (the 8-feature structure layer and the 2-class head always run in fp32).  Everything
+ * else -- normalisation, softmax, activations, accumulation -- is fp32 in every mode.  No counterpart in the reference (Keras runs the
  * graph in fp32).
  *   DPTM_PREC_F32    fp32 MFMA (default); probabilities within 1e-4 of the fp32 reference
  *   DPTM_PREC_BF16   operands rounded to bfloat16
@@ -159,6 +159,17 @@ int dptm_set_precision(dptm_handle* h, int mode);
 int64_t dptm_chunk_sites(const dptm_handle* h);
 
 const char* dptm_last_error(void);
+
+/* Solvent-accessible surface area per atom, Shrake-Rupley with `probe` (Angstrom) and the caller's
+ * `n_points` unit-sphere test points: replaces the per-residue SASA the reference takes from
+ * PyRosetta (pred/train_PTM/predict.py:210-241, calc_per_atom_sasa with probe 1.4) in the
+ * structure-feature stage in front of the scoring path.  Host buffers: xyz [n][3], radii [n]
+ * (<= 0: atom ignored), unit_points [n_points][3], area_out [n], all double.  Counts are exact
+ * integer work, so results are bit-identical to the NumPy restatement in
+ * deepptmpred_amd/structure.py.  Errors through dptm_sasa_last_error(). */
+int dptm_sasa(const double* xyz, const double* radii, int64_t n, double probe, const double* unit_points,
+              int32_t n_points, int32_t device, double* area_out);
+const char* dptm_sasa_last_error(void);
 
 /* ------------------------------------------------------------------------------------
  * Training step.  Replaces what model.fit runs per batch in the reference

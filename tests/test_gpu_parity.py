@@ -220,3 +220,32 @@ def test_ptm_type_sweep_on_gpu(weights, golden_dir, tmp_path):
     toks = [O.encode_sequences(O.get_sequence_windows(full, list(pos), w)) for w in (21, 33, 51)]
     ref = oracle(spec.synthetic_weights(100), toks + [calc.features(pos), np.zeros((len(pos), 1280))])[:, 1]
     assert np.abs(res["ubiquitination"]["probability"].to_numpy() - ref).max() < TOL
+
+
+def test_gpu_sasa_bit_exact(golden_dir):
+    """dptm_sasa counts exposed test points exactly like the host implementation: identical areas,
+    on a real structure excerpt and on a dense random cloud (ragged: isolated atoms, ignored atoms)."""
+    import time
+    from deepptmpred_amd import structure as S
+    atoms = S.PdbAtoms(os.path.join(golden_dir, "akt1_head60.pdb"))
+    radii = np.array([S._atom_radius(atoms.resnames[i], atoms.names[i], atoms.elements[i]) for i in range(len(atoms.names))])
+    host = S.shrake_rupley(atoms.xyz, radii)
+    dev = S.shrake_rupley(atoms.xyz, radii, backend="hip")
+    assert np.array_equal(host, dev)
+    fx = np.load(os.path.join(golden_dir, "structure_akt1.npz"))
+    per_res = np.bincount(atoms.residue_index, weights=dev, minlength=61)
+    assert np.abs(per_res - fx["head_sasa_per_residue"]).max() < 1e-9       # the brute-force oracle's numbers
+    rng = np.random.default_rng(3)
+    n = 6000
+    xyz = rng.uniform(0, 45, size=(n, 3))
+    xyz[:5] += 500.0                                  # isolated atoms: full spheres
+    r = rng.choice([1.4, 1.65, 1.76, 1.87], size=n)
+    r[100:120] = 0.0                                  # ignored atoms (hydrogens)
+    t0 = time.perf_counter(); host = S.shrake_rupley(xyz, r); t1 = time.perf_counter()
+    dev = S.shrake_rupley(xyz, r, backend="hip"); t2 = time.perf_counter()
+    print("sasa %d atoms: host %.3f s, gpu (incl. transfers) %.4f s" % (n, t1 - t0, t2 - t1))
+    assert np.array_equal(host, dev)
+    assert dev[0] == pytest.approx(4 * np.pi * (r[0] + 1.4) ** 2) and (dev[100:120] == 0).all()
+    assert S.shrake_rupley(np.zeros((0, 3)), np.zeros(0), backend="hip").shape == (0,)
+    calc = S.StructureCalculator(os.path.join(golden_dir, "akt1_head60.pdb"), sasa_backend="hip")
+    assert calc.res_sasa[7][0] == per_res[7]
