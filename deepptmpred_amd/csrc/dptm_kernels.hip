@@ -19,6 +19,7 @@ namespace dptm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void mfma(f32x16& acc, float a, float b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
@@ -346,14 +347,16 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
                     const f32x4 k1 = *reinterpret_cast<const f32x4*>(kp + t * kLdsStride + 4);
                     const f32x4 k2 = *reinterpret_cast<const f32x4*>(kp + t * kLdsStride + 8);
                     const f32x4 k3 = *reinterpret_cast<const f32x4*>(kp + t * kLdsStride + 12);
-                    float a = 0.f;
+                    // two partial sums so that the 16 products go through 8 packed FMAs
+                    f32x2 a2 = {0.f, 0.f};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        a = fmaf(qa[8 * hd + e], k0[e], a);
-                        a = fmaf(qb[8 * hd + e], k1[e], a);
-                        a = fmaf(qa[8 * hd + 4 + e], k2[e], a);
-                        a = fmaf(qb[8 * hd + 4 + e], k3[e], a);
+                    for (int e = 0; e < 4; e += 2) {
+                        a2 += f32x2{qa[8 * hd + e], qa[8 * hd + e + 1]} * f32x2{k0[e], k0[e + 1]};
+                        a2 += f32x2{qb[8 * hd + e], qb[8 * hd + e + 1]} * f32x2{k1[e], k1[e + 1]};
+                        a2 += f32x2{qa[8 * hd + 4 + e], qa[8 * hd + 5 + e]} * f32x2{k2[e], k2[e + 1]};
+                        a2 += f32x2{qb[8 * hd + 4 + e], qb[8 * hd + 5 + e]} * f32x2{k3[e], k3[e + 1]};
                     }
+                    const float a = a2[0] + a2[1];
                     sc[t] = a;
                     cm = fmaxf(cm, a);
                 }
