@@ -22,7 +22,8 @@ dst = os.path.join(root, "profiles")
 def per_kernel(pattern):
     """{kernel family: {counter: [values per dispatch]}} from a counter_collection csv"""
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(src, pattern, "*", "*counter_collection.csv")):
+    files = sorted(glob.glob(os.path.join(src, pattern, "*", "*counter_collection.csv")), key=os.path.getmtime)
+    for f in files[-1:]:                 # the most recent pass only (gpurun merges new files next to old ones)
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0]
             if "branch_kernel" in name or "dense_kernel" in name:
@@ -68,7 +69,7 @@ for prec in ("f32", "f16x3", "bf16"):
                          "mfma_busy_frac_of_simd_cycles": busy / (1024 * dur * clk)}
 json.dump(traffic, open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1)
 json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1)
-for f in glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")):
+for f in sorted(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")), key=os.path.getmtime)[-1:]:
     shutil.copy(f, os.path.join(dst, tag + "_kernel_stats.csv"))
 tb = os.path.join(src, "trace_bench.json")
 if os.path.exists(tb):
