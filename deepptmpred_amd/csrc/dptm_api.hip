@@ -145,6 +145,8 @@ struct dptm_handle {
     float* d_branch[3] = {nullptr, nullptr, nullptr};
     uint16_t* d_branch_half[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // [branch][bf16 | f16 hi | f16 lo]
     int precision = kModeF32;
+    std::vector<float> blob;              // canonical weights, kept to build the half-precision images on demand
+    bool half_ready = false;
     DenseLayer strct, esm1, esm2, t1, t2, head;
     // per-chunk workspace
     float* d_concat = nullptr;
@@ -214,14 +216,18 @@ int upload(const std::vector<float>& v, float** d) {
 
 // Packs one sequence branch (tensor order of spec.py:tensor_table) into the buffer
 // layout of dptm_layout.h.
-void pack_branch(Reader& rd, int W, std::vector<float>& buf, std::vector<uint16_t> (&half)[3]) {
+void pack_branch(Reader& rd, int W, std::vector<float>& buf, std::vector<uint16_t> (&half)[3], bool want_half) {
     buf.assign((size_t)kBranchF4 * 4, 0.0f);
-    for (auto& hbuf : half) hbuf.assign((size_t)kBranchF4 * 4, 0);   // same offsets, in 16-bit units: float4 offset/2 = uint4 offset
+    if (want_half)
+        for (auto& hbuf : half) hbuf.assign((size_t)kBranchF4 * 4, 0);   // same offsets, in 16-bit units: float4 offset/2 = uint4 offset
     float* B = buf.data();
     auto f4 = [&](int off) { return B + (size_t)off * 4; };
     // a matrix at float4 offset `off` has its half images at uint4 offset off/2 = 16-bit offset off*4
     auto pack_matrix = [&](const float* Wm, int K, int N, int n_pad, float* dst) {
-        ::pack_matrix(Wm, K, N, n_pad, dst);
+        if (!want_half) {
+            ::pack_matrix(Wm, K, N, n_pad, dst);
+            return;
+        }
         const size_t off16 = (size_t)(dst - B);   // floats from the start == 16-bit units of the half image
         for (int kind = 0; kind < 3; ++kind) pack_matrix_half(Wm, K, N, kind, half[kind].data() + off16);
     };
@@ -280,14 +286,7 @@ int make_dense(Reader& rd, int K, int N, int n_pad, bool bn, DenseLayer& L) {
     pack_matrix(Wm, K, N, n_pad, w.data());
     int rc = upload(w, &L.d_w);
     if (rc) return rc;
-    if (K % 16 == 0 && N == n_pad && N % 128 == 0) {
-        std::vector<uint16_t> hw((size_t)K * N);
-        for (int kind = 0; kind < 3; ++kind) {
-            pack_matrix_half(Wm, K, N, kind, hw.data());
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&L.d_w_half[kind]), hw.size() * sizeof(uint16_t)));
-            HIP_TRY(hipMemcpy(L.d_w_half[kind], hw.data(), hw.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-        }
-    }
+    (void)Wm;
     pack_vector(rd.take(N), N, n_pad, v.data());
     rc = upload(v, &L.d_bias);
     if (rc) return rc;
@@ -302,6 +301,18 @@ int make_dense(Reader& rd, int K, int N, int n_pad, bool bn, DenseLayer& L) {
         pack_vector(sh.data(), N, n_pad, v.data());
         rc = upload(v, &L.d_shift);
         if (rc) return rc;
+    }
+    return DPTM_OK;
+}
+
+// half-precision images of a dense layer's kernel (layers with k % 16 == 0 and n % 128 == 0 only)
+int make_dense_half(const float* Wm, int K, int N, DenseLayer& L) {
+    if (K % 16 != 0 || N % 128 != 0) return DPTM_OK;
+    std::vector<uint16_t> hw((size_t)K * N);
+    for (int kind = 0; kind < 3; ++kind) {
+        pack_matrix_half(Wm, K, N, kind, hw.data());
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&L.d_w_half[kind]), hw.size() * sizeof(uint16_t)));
+        HIP_TRY(hipMemcpy(L.d_w_half[kind], hw.data(), hw.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     return DPTM_OK;
 }
@@ -451,6 +462,37 @@ int ensure_pipeline(dptm_handle* h) {
     return DPTM_OK;
 }
 
+// bf16 / f16 hi / f16 lo images of every matrix the half-precision kernels read, built the first time a
+// half-precision mode is selected (the fp32 default never pays for them)
+int build_half_images(dptm_handle* h) {
+    HIP_TRY(hipSetDevice(h->device));
+    Reader rd{h->blob.data()};
+    std::vector<float> buf;
+    std::vector<uint16_t> half[3];
+    for (int b = 0; b < 3; ++b) {
+        pack_branch(rd, kWin[b], buf, half, true);
+        for (int kind = 0; kind < 3; ++kind) {
+            const size_t bytes = half[kind].size() * sizeof(uint16_t);
+            if (!h->d_branch_half[b][kind]) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->d_branch_half[b][kind]), bytes));
+            HIP_TRY(hipMemcpy(h->d_branch_half[b][kind], half[kind].data(), bytes, hipMemcpyHostToDevice));
+        }
+    }
+    struct { int k, n; bool bn; DenseLayer* L; } layers[] = {
+        {kStruct, kStructUnits, true, &h->strct}, {kEsm, kEsm1, true, &h->esm1}, {kEsm1, kEsm2, false, &h->esm2},
+        {kConcat, kT1, true, &h->t1}, {kT1, kT2, true, &h->t2}};
+    for (auto& l : layers) {
+        const float* Wm = rd.take((size_t)l.k * l.n);
+        rd.take(l.n);                                   // bias
+        if (l.bn) rd.take(4 * (size_t)l.n);             // gamma, beta, moving mean, moving variance
+        if (!l.L->d_w_half[0]) {
+            int rc = make_dense_half(Wm, l.k, l.n, *l.L);
+            if (rc) return rc;
+        }
+    }
+    h->half_ready = true;
+    return DPTM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -539,19 +581,13 @@ int dptm_create(const void* weights, size_t nbytes, const dptm_spec* spec, int d
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(DPTM_EHIP, "dptm_create: hipStreamCreate failed"));
 
-    Reader rd{static_cast<const float*>(weights)};
+    h->blob.assign(static_cast<const float*>(weights), static_cast<const float*>(weights) + want);
+    Reader rd{h->blob.data()};
     std::vector<float> buf;
     std::vector<uint16_t> half[3];
     for (int b = 0; b < 3; ++b) {
-        pack_branch(rd, kWin[b], buf, half);
+        pack_branch(rd, kWin[b], buf, half, false);
         if ((rc = upload(buf, &h->d_branch[b]))) return bail(rc);
-        for (int kind = 0; kind < 3; ++kind) {
-            const size_t bytes = half[kind].size() * sizeof(uint16_t);
-            if (hipMalloc(reinterpret_cast<void**>(&h->d_branch_half[b][kind]), bytes) != hipSuccess)
-                return bail(fail(DPTM_ENOMEM, "dptm_create: device allocation failed"));
-            if (hipMemcpy(h->d_branch_half[b][kind], half[kind].data(), bytes, hipMemcpyHostToDevice) != hipSuccess)
-                return bail(fail(DPTM_EHIP, "dptm_create: upload failed"));
-        }
     }
     if ((rc = make_dense(rd, kStruct, kStructUnits, kStructUnits, true, h->strct))) return bail(rc);
     if ((rc = make_dense(rd, kEsm, kEsm1, kEsm1, true, h->esm1))) return bail(rc);
@@ -559,7 +595,7 @@ int dptm_create(const void* weights, size_t nbytes, const dptm_spec* spec, int d
     if ((rc = make_dense(rd, kConcat, kT1, kT1, true, h->t1))) return bail(rc);
     if ((rc = make_dense(rd, kT1, kT2, kT2, true, h->t2))) return bail(rc);
     if ((rc = make_dense(rd, kT2, 2, 32, false, h->head))) return bail(rc);
-    if (rd.p - static_cast<const float*>(weights) != want)
+    if (rd.p - h->blob.data() != want)
         return bail(fail(DPTM_EINVAL, "dptm_create: internal weight-order mismatch"));
 
     auto dalloc = [&](void** p, size_t bytes) -> int {
@@ -586,6 +622,10 @@ int dptm_set_precision(dptm_handle* h, int mode) {
     if (!h) return fail(DPTM_EINVAL, "dptm_set_precision: NULL handle");
     if (mode != kModeF32 && mode != kModeBF16 && mode != kModeF16 && mode != kModeF16X3)
         return fail(DPTM_EINVAL, "dptm_set_precision: unknown mode");
+    if (mode != kModeF32 && !h->half_ready) {
+        int rc = build_half_images(h);
+        if (rc) return rc;
+    }
     h->precision = mode;
     return DPTM_OK;
 }
@@ -663,6 +703,19 @@ int dptm_score(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const
     HIP_TRY(hipSetDevice(h->device));
     int rc = ensure_host_staging(h);
     if (rc) return rc;
+    if (n <= kChunkSites) {
+        // one pass: nothing to overlap, and the pinned staging blocks of the pipeline (2 x 172 MB) are not
+        // worth allocating for a protein's worth of sites
+        for (int b = 0; b < 3; ++b)
+            HIP_TRY(hipMemcpyAsync(h->s_tok[b], (b == 0 ? tok21 : b == 1 ? tok33 : tok51), n * kWin[b], hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->s_strct, strct, n * kStruct * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->s_esm, esm, n * (size_t)kEsm * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        const uint8_t* tok[3] = {h->s_tok[0], h->s_tok[1], h->s_tok[2]};
+        if ((rc = score_chunk(h, tok, h->s_strct, h->s_esm, kEsm, nullptr, n, h->s_out, h->stream))) return rc;
+        HIP_TRY(hipMemcpyAsync(out, h->s_out, n * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        return DPTM_OK;
+    }
     if ((rc = ensure_pipeline(h))) return rc;
     // Two staging slots.  Per chunk: the host gathers the caller's (pageable) rows into a pinned block with a few
     // threads, the copy stream moves that block over PCIe, the handle's stream scores it.  The gather of chunk i+1

@@ -96,15 +96,17 @@ class PredictConfig:
 class PTMPredictDataLoader:
     """predict.py:437-560."""
 
-    def __init__(self, config: PredictConfig, struct_calculator=None):
+    def __init__(self, config: PredictConfig, struct_calculator=None, sasa_backend: str = "numpy", device: int = 0):
         self.config = config
         self.rosetta_calc = struct_calculator
+        self.sasa_backend = sasa_backend      # "hip": surface areas on the GPU (bit-identical to "numpy")
+        self.device = device
 
     def init_pyrosetta(self, pdb_path):
         """predict.py:442-445 (name kept): lazily builds the structure calculator for a PDB file."""
         if self.rosetta_calc is None:
             from .structure import StructureCalculator
-            self.rosetta_calc = StructureCalculator(pdb_path)
+            self.rosetta_calc = StructureCalculator(pdb_path, sasa_backend=self.sasa_backend, device=self.device)
 
     def load_custom_esm(self, protein_id: str):
         path = os.path.join(self.config.custom_esm_dir, f"{protein_id}_full_esm.npz")
@@ -173,7 +175,8 @@ class PTMPredictor:
 
     def __init__(self, config: PredictConfig, model: Optional[Model] = None, struct_calculator=None, device: int = 0):
         self.config = config
-        self.data_loader = PTMPredictDataLoader(config, struct_calculator)
+        # the predictor owns a GPU model, so the structure stage uses the GPU for its surface areas too
+        self.data_loader = PTMPredictDataLoader(config, struct_calculator, sasa_backend="hip", device=device)
         self.model = model if model is not None else load_model(config.model_path, device=device)
 
     def predict_ptm_sites(self, protein_id, protein_sequence, positions=None, pdb_path=None, struct_features=None,

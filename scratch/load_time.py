@@ -1,0 +1,21 @@
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from deepptmpred_amd import spec
+from deepptmpred_amd.model import Model, load_model
+w = spec.synthetic_weights(7)
+spec.save_flat("/tmp/w.dptm", w)
+m = Model(w); m.predict(spec.synthetic_inputs(8, 1)); m.close()
+for rep in range(3):
+    t0 = time.perf_counter(); m = load_model("/tmp/w.dptm"); t1 = time.perf_counter()
+    p = m.predict(spec.synthetic_inputs(53, 1)); t2 = time.perf_counter()
+    m.close()
+    print("load_model %.1f ms (incl. first scorer build lazily?), first predict of 53 sites %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
+m = load_model("/tmp/w.dptm"); m.predict(spec.synthetic_inputs(53, 1))
+t0 = time.perf_counter()
+for _ in range(20): m.predict(spec.synthetic_inputs(53, 1))
+print("steady predict of 53 sites incl. input synthesis %.2f ms" % ((time.perf_counter() - t0) / 20 * 1e3))
+x = spec.synthetic_inputs(53, 1)
+t0 = time.perf_counter()
+for _ in range(50): m.predict(x)
+print("steady predict of 53 sites %.3f ms" % ((time.perf_counter() - t0) / 50 * 1e3))
