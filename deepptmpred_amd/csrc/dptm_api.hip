@@ -142,6 +142,8 @@ struct ProfRec {
 struct dptm_handle {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};     // side streams of the small-call path
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     float* d_branch[3] = {nullptr, nullptr, nullptr};
     uint16_t* d_branch_half[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // [branch][bf16 | f16 hi | f16 lo]
     int precision = kModeF32;
@@ -365,10 +367,10 @@ int run_dense(dptm_handle* h, const DenseLayer& L, int epi, const float* x, int6
     a.ldo = ldo;
     a.col_off = col_off;
     Prof p(h, st, cls);
-    if (h->precision != kModeF32 && L.d_w_half[0] && epi != kEpiHead) {
+    if (h->precision != kModeF32 && L.d_w_half[0] && epi != kEpiHead && m > kDenseSmallRows) {
         HIP_TRY(launch_dense_h(h->precision, a, epi, L.d_w_half[h->precision == kModeBF16 ? 0 : 1], L.d_w_half[2], st));
     } else {
-        HIP_TRY(launch_dense(a, epi, st));   // fp32: the 8-feature structure layer, the 2-class head
+        HIP_TRY(launch_dense(a, epi, st));   // fp32: the 8-feature structure layer, the 2-class head, small calls
     }
     return DPTM_OK;
 }
@@ -376,15 +378,32 @@ int run_dense(dptm_handle* h, const DenseLayer& L, int epi, const float* x, int6
 // One chunk (m <= kChunkSites) of the forward pass, everything device-resident.
 int score_chunk(dptm_handle* h, const uint8_t* const tok[3], const float* strct, const float* esm,
                 int64_t esm_ld, const int32_t* esm_row, int64_t m, float* out, hipStream_t st) {
+    // A small call cannot fill the chip with any one kernel, so its three sequence branches run on side
+    // streams next to the structure / ESM layers; a large call keeps everything on one stream.
+    const bool fan_out = m <= kDenseSmallRows && !h->prof_armed;
+    if (fan_out && !h->ev_fork) {
+        for (int b = 0; b < 3; ++b) {
+            HIP_TRY(hipStreamCreateWithFlags(&h->aux[b], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_join[b], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    }
+    if (fan_out) HIP_TRY(hipEventRecord(h->ev_fork, st));
     for (int b = 0; b < 3; ++b) {
-        Prof p(h, st, DPTM_PROF_BRANCH21 + b);
+        hipStream_t bs = st;
+        if (fan_out) {
+            bs = h->aux[b];
+            HIP_TRY(hipStreamWaitEvent(bs, h->ev_fork, 0));
+        }
+        Prof p(h, bs, DPTM_PROF_BRANCH21 + b);
         if (h->precision == kModeF32) {
-            HIP_TRY(launch_branch(kWin[b], h->d_branch[b], tok[b], m, h->d_concat, kConcat, b * kD, st));
+            HIP_TRY(launch_branch(kWin[b], h->d_branch[b], tok[b], m, h->d_concat, kConcat, b * kD, bs));
         } else {
             const uint16_t* hi = h->d_branch_half[b][h->precision == kModeBF16 ? 0 : 1];
             HIP_TRY(launch_branch_h(h->precision, kWin[b], h->d_branch[b], hi, h->d_branch_half[b][2], tok[b], m,
-                                    h->d_concat, kConcat, b * kD, st));
+                                    h->d_concat, kConcat, b * kD, bs));
         }
+        if (fan_out) HIP_TRY(hipEventRecord(h->ev_join[b], bs));
     }
     int rc;
     if ((rc = run_dense(h, h->strct, kEpiSwishAffine, strct, kStruct, nullptr, m, h->d_concat, kConcat,
@@ -396,6 +415,8 @@ int score_chunk(dptm_handle* h, const uint8_t* const tok[3], const float* strct,
     if ((rc = run_dense(h, h->esm2, kEpiSwish, h->d_h1, kEsm1, nullptr, m, h->d_concat, kConcat,
                         3 * kD + kStructUnits, st, DPTM_PROF_ESM2)))
         return rc;
+    if (fan_out)
+        for (int b = 0; b < 3; ++b) HIP_TRY(hipStreamWaitEvent(st, h->ev_join[b], 0));
     if ((rc = run_dense(h, h->t1, kEpiSwishAffine, h->d_concat, kConcat, nullptr, m, h->d_t1, kT1, 0, st,
                         DPTM_PROF_TRUNK1)))
         return rc;
@@ -520,6 +541,14 @@ void dptm_destroy(dptm_handle* h) {
         if (h->s_tok[b]) (void)hipFree(h->s_tok[b]);
         if (h->s2_tok[b]) (void)hipFree(h->s2_tok[b]);
     }
+    for (int b = 0; b < 3; ++b) {
+        if (h->aux[b]) {
+            (void)hipStreamSynchronize(h->aux[b]);
+            (void)hipStreamDestroy(h->aux[b]);
+        }
+        if (h->ev_join[b]) (void)hipEventDestroy(h->ev_join[b]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->copy_stream) {
         (void)hipStreamSynchronize(h->copy_stream);
         (void)hipStreamDestroy(h->copy_stream);

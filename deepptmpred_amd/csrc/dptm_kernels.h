@@ -10,6 +10,9 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 enum DenseEpilogue { kEpiSwish = 0, kEpiSwishAffine = 1, kEpiHead = 2 };
 
+// calls of at most this many rows (a protein's worth of sites) use the latency-oriented kernels and streams
+constexpr int64_t kDenseSmallRows = 512;
+
 // arithmetic of the matrix products in the fused sequence branch (DPTM_PREC_* in dptm.h)
 enum PrecisionMode { kModeF32 = 0, kModeBF16 = 1, kModeF16 = 2, kModeF16X3 = 3 };
 

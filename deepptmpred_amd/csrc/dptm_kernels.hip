@@ -594,6 +594,72 @@ __global__ __launch_bounds__(256) void dense_kernel(DenseArgs p) {
 }
 
 // ------------------------------------------------------------------------------------
+// The same dense layer for a handful of rows (one protein's sites): a 64x128 tile per wavefront would
+// leave the chip idle and walk the whole contraction in one wavefront.  Here a workgroup owns 32 rows x
+// 32 columns and its 8 wavefronts split the contraction; partial tiles meet in LDS, where the bias and
+// the epilogue are applied.  grid = (ceil(m/32), n_pad/32), block 512.
+// ------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512) void dense_small_kernel(DenseArgs p) {
+    __shared__ float part[8][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const int64_t r0 = (int64_t)blockIdx.x * 32;
+    const int tile = blockIdx.y;
+    const int k8 = p.k >> 3;
+    const int per = (k8 + 7) / 8;
+    const int u0 = wave * per, u1 = min(k8, u0 + per);
+    int64_t r = r0 + j;
+    if (r > p.m - 1) r = p.m - 1;
+    int64_t src = r;
+    bool ok = true;
+    if (p.row_index) {
+        const int32_t s = p.row_index[r];
+        ok = s >= 0;
+        src = s >= 0 ? s : 0;
+    }
+    const float* xrow = p.x + src * p.ldx + 4 * h;
+    const f32x4* wp = p.w + (size_t)tile * k8 * 64 + lane;
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int ub = u0; ub < u1; ub += 4) {      // four steps of operands in flight
+        f32x4 a[4], b[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            a[v] = b[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ub + v < u1) {
+                a[v] = wp[(size_t)(ub + v) * 64];
+                if (ok) b[v] = *reinterpret_cast<const f32x4*>(xrow + 8 * (ub + v));
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mfma(acc, a[v][e], b[v][e]);
+    }
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) part[wave][rg][lane] = acc[rg];
+    __syncthreads();
+    // 1024 outputs of the tile, two per thread: register rg of lane l is row r0 + (l & 31), feature
+    // 8*(rg>>2) + 4*(l>>5) + (rg&3) of this 32-column tile
+    for (int o = threadIdx.x; o < 1024; o += 512) {
+        const int rg = o >> 6, l = o & 63;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += part[w][rg][l];
+        const int hh = l >> 5;
+        const int g = rg >> 2, e = rg & 3;
+        const int vi = hh * (p.n_pad >> 3) + tile * 4 + g;     // packed-vector group of this feature
+        v += reinterpret_cast<const float*>(p.bias + vi)[e];
+        const int64_t row = r0 + (l & 31);
+        if (row >= p.m) continue;
+        if (EPI == kEpiSwish || EPI == kEpiSwishAffine) v = swishf(v);
+        if (EPI == kEpiSwishAffine)
+            v = fmaf(v, reinterpret_cast<const float*>(p.scale + vi)[e], reinterpret_cast<const float*>(p.shift + vi)[e]);
+        p.out[row * p.ldo + p.col_off + tile * 32 + 8 * g + 4 * hh + e] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Window assembly (predict.py:529-560): column c of the window of 1-based position
 // `pos` is sequence index pos-1-half+c, or the padding code 20 outside 0..L-1.
 // One thread per output byte of the widest layout; rows are contiguous so the byte
@@ -668,6 +734,17 @@ hipError_t launch_branch(int w, const float* params, const uint8_t* tok, int64_t
 
 hipError_t launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
     if (a.m == 0) return hipSuccess;
+    if (a.m <= kDenseSmallRows && epi != kEpiHead) {
+        if (a.n_pad % 32 != 0) return hipErrorInvalidValue;
+        const dim3 grid((unsigned)((a.m + 31) / 32), (unsigned)(a.n_pad / 32));
+        if (epi == kEpiSwish)
+            hipLaunchKernelGGL((dense_small_kernel<kEpiSwish>), grid, dim3(512), 0, st, a);
+        else if (epi == kEpiSwishAffine)
+            hipLaunchKernelGGL((dense_small_kernel<kEpiSwishAffine>), grid, dim3(512), 0, st, a);
+        else
+            return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     const unsigned gx = (unsigned)((a.m + 255) / 256);
     if (epi == kEpiHead) {
         hipLaunchKernelGGL((dense_kernel<1, kEpiHead>), dim3(gx, 1), dim3(256), 0, st, a);
