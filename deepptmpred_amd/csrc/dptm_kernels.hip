@@ -706,7 +706,11 @@ static constexpr size_t kBranchLds = (2 * kTileRows * kLdsStride + kTileRows) * 
 template <int W>
 static hipError_t launch_branch_t(const float* params, const uint8_t* tok, int64_t n, float* out,
                                   int ldo, int col_off, hipStream_t st) {
-    static bool attr_done = false;
+    // the LDS opt-in is per device: remember which devices of this process have it
+    static bool attr_done_dev[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    bool& attr_done = attr_done_dev[dev];
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&branch_kernel<W>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
