@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/ab_full.sh "precisions" lib...  : default 1M-site bench per library
+# usage: tools/ab_bench.sh "precisions" lib...  : default 1M-site bench per library
 PRECS="$1"; shift
 for lib in "$@"; do for prec in $PRECS; do
   echo "== $lib $prec"

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/tools_ab.sh [-p "f32 f16x3 ..."] lib1.so [lib2.so ...]  (A/B kernel timings of several builds / precisions on the GPU box)
+# usage: tools/ab_kernels.sh [-p "f32 f16x3 ..."] lib1.so [lib2.so ...]  (A/B kernel timings of several builds / precisions on the GPU box)
 PRECS="f32"
 if [ "$1" = "-p" ]; then PRECS="$2"; shift 2; fi
 for lib in "$@"; do

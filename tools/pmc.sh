@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/pmc.sh <precision> <tag> [counters...] ; collects SQ counters for the branch kernels
+# usage: tools/pmc.sh <precision> <tag> [counters...] ; collects SQ counters for the branch kernels
 prec=$1; tag=$2; shift 2
 ctrs="$@"
 [ -z "$ctrs" ] && ctrs="GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
