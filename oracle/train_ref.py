@@ -11,7 +11,7 @@ PARITY UNPINNED: the reference's training step is ``model.fit`` on a Keras graph
   embedding (model.py:159).  Keras' dropout random stream cannot be reproduced, so masks
   come from a stateless 32-bit hash of (seed, stream id, element index) that the HIP
   kernels implement identically; rate 0 disables a site.
-* loss (trainer.py:36-54) under the interpretation recorded in SURVEY.md 8a-T: labels =
+* loss (trainer.py:36-54) under this interpretation of the Keras call: labels =
   argmax(y_true); N, N_pos over the (global) batch; w_pos = N/(2 N_pos + eps), w_neg =
   N/(2 N_neg + eps), eps = 1e-7; per-sample weight broadcast over both softmax columns
   times keras.backend.binary_crossentropy(y_onehot, y_pred) (probabilities clipped to

@@ -18,7 +18,7 @@ def weights():
 
 
 def test_param_count():
-    # SURVEY 8a: 1,620,229 parameters (1,616,645 trainable + 3,584 BN moving statistics)
+    # 1,620,229 parameters (1,616,645 trainable + 3,584 BN moving statistics)
     assert spec.n_params() == 1_620_229
     bn_stats = sum(int(np.prod(s)) for n, s in spec.tensor_table() if n.endswith((".mean", ".var")))
     assert bn_stats == 3584
