@@ -227,6 +227,7 @@ def main() -> None:
     n = args.sites
     x = device_inputs(n, 1234 + rank, dev)
     out = torch.empty((n, 2), device=dev, dtype=torch.float32)
+    torch.cuda.synchronize()     # inputs are complete before any library stream reads them
     stream = torch.cuda.current_stream().cuda_stream
     ptrs = [t.data_ptr() for t in x]
 

@@ -61,3 +61,47 @@ def predict_sharded(score_fn: Callable[[List[np.ndarray]], np.ndarray], x: Seque
         a, b = shard_range(n, r, world)
         out[a:b] = p[: b - a].cpu().numpy()
     return out
+
+
+def predict_all_types(models, x: Sequence[np.ndarray], pass_sites: int = 262144) -> dict:
+    """Scores the same sites with several weight sets (the 17 PTM types of predict.py:119-137).
+
+    ``models`` maps a name to a ``Model`` on this process's GPU.  The inputs cross PCIe ONCE
+    per pass of ``pass_sites`` sites (pinned staging, device buffers from torch) and every
+    model scores the resident pass through the device-pointer entry point, so the upload
+    cost is shared by all types; results are float32 ``[N,2]`` per name.  Combine with
+    ``shard_inputs`` to spread the sites over the GPUs of a node (shard by sites, not by
+    type: every rank stays balanced and every input is uploaded once)."""
+    import torch
+
+    names = list(models)
+    n = len(x[0])
+    out = {k: np.empty((n, 2), dtype=np.float32) for k in names}
+    if n == 0 or not names:
+        return out
+    first = models[names[0]]
+    dev = torch.device(f"cuda:{first.device}")
+    torch.cuda.set_device(dev)
+    # an explicit stream: a NULL stream argument means "the handle's own stream" to the library, which
+    # would not be ordered after the uploads torch issues on its default stream
+    tstream = torch.cuda.Stream(device=dev)
+    stream = tstream.cuda_stream
+    ws = first.spec.window_sizes
+    dtypes = [np.uint8, np.uint8, np.uint8, np.float32, np.float32]
+    widths = [ws[0], ws[1], ws[2], first.spec.struct_feature_dim, first.spec.esm_dim]
+    cap = min(pass_sites, n)
+    stage = [torch.empty((cap, w), dtype=torch.uint8 if d is np.uint8 else torch.float32).pin_memory()
+             for w, d in zip(widths, dtypes)]
+    dbuf = [torch.empty((cap, w), dtype=s.dtype, device=dev) for w, s in zip(widths, stage)]
+    dout = torch.empty((cap, 2), dtype=torch.float32, device=dev)
+    with torch.cuda.stream(tstream):
+        for lo in range(0, n, cap):
+            m = min(cap, n - lo)
+            for s, d, a, dt in zip(stage, dbuf, x, dtypes):
+                s[:m].copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(a)[lo:lo + m], dtype=dt)))
+                d[:m].copy_(s[:m], non_blocking=True)
+            for k in names:
+                models[k].scorer.score_device(dbuf[0].data_ptr(), dbuf[1].data_ptr(), dbuf[2].data_ptr(),
+                                              dbuf[3].data_ptr(), dbuf[4].data_ptr(), m, dout.data_ptr(), stream)
+                out[k][lo:lo + m] = dout[:m].cpu().numpy()      # synchronises the stream
+    return out

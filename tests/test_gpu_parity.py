@@ -262,3 +262,15 @@ def test_host_pipeline_three_passes(model):
     p = model.predict(x)
     base = model.predict(small)                                  # one pass, direct path
     assert np.array_equal(p, np.tile(base, (reps, 1))[:n])
+
+
+def test_predict_all_types_shares_one_upload(weights):
+    """Several weight sets over the same resident inputs give what each model gives alone."""
+    from deepptmpred_amd.sharding import predict_all_types
+    ms = {"a": Model(weights), "b": Model(spec.synthetic_weights(100)), "c": Model(spec.synthetic_weights(101))}
+    x = spec.synthetic_inputs(3001, 17)
+    res = predict_all_types(ms, x, pass_sites=1024)          # three passes, ragged tail
+    for k, m in ms.items():
+        assert np.array_equal(res[k], m.predict(x))
+        m.close()
+    assert predict_all_types({}, x) == {}
