@@ -118,9 +118,16 @@ struct dptm_trainer {
     BranchAct ba[3];
     // per-site tensors
     float *sa, *sy, *smi, *ea, *ey, *emi, *e1, *e2a, *concat, *t1a, *t1y, *t1mi, *t1z, *t2a, *t2y, *t2mi, *t2z, *proba;
-    float *d_loss = nullptr, *bnstat = nullptr, *bnsums = nullptr;
-    // gradient scratch
-    float *g64a, *g64b, *g64c, *g64d, *g256, *gq, *gk, *gv;   // [maxrows][64] / [maxrows][256]
+    float* d_loss = nullptr;
+    // Scratch of one concurrent lane of the step: the three sequence branches run on side streams next to
+    // the per-site layers, so each owns its gradient scratch ([rows][64] / [rows][256]) and BatchNorm sums.
+    struct Scratch {
+        float *g64a = nullptr, *g64b = nullptr, *g64c = nullptr, *g64d = nullptr, *g256 = nullptr;
+        float *gq = nullptr, *gk = nullptr, *gv = nullptr, *bnstat = nullptr, *bnsums = nullptr;
+    };
+    Scratch sc[4];                        // [0..2] sequence branches, [3] per-site layers (BatchNorm sums only)
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
     float *dconcat, *d512a, *d512b, *d256a, *d256b, *d128;
     int64_t step = 0;
     int64_t last_n = 0;
@@ -140,7 +147,7 @@ struct dptm_trainer {
     GraphKey gkey;
     int gkey_hits = 0;                    // consecutive eager calls with gkey
     hipGraphExec_t gexec = nullptr;
-    bool use_graph = true;
+    bool use_graph = false;               // opt-in (DPTM_TRAIN_GRAPH=1): replay measures slower than eager multi-stream issue
 };
 
 namespace {
@@ -171,11 +178,16 @@ int alloc_acts(dptm_trainer* t) {
           need(t->emi, 1024) && need(t->e1, B * 512) && need(t->e2a, B * 256) && need(t->concat, B * 576) &&
           need(t->t1a, B * 512) && need(t->t1y, B * 512) && need(t->t1mi, 1024) && need(t->t1z, B * 512) &&
           need(t->t2a, B * 256) && need(t->t2y, B * 256) && need(t->t2mi, 512) && need(t->t2z, B * 256) &&
-          need(t->proba, B * 2) && need(t->d_loss, 64) && need(t->bnstat, 1024) && need(t->bnsums, 1024);
-    const size_t RM = (size_t)B * 51;
-    ok &= need(t->g64a, RM * 64) && need(t->g64b, RM * 64) && need(t->g64c, RM * 64) && need(t->g64d, RM * 64) &&
-          need(t->g256, RM * 256) && need(t->gq, RM * 64) && need(t->gk, RM * 64) && need(t->gv, RM * 64) &&
-          need(t->dconcat, B * 576) && need(t->d512a, B * 512) && need(t->d512b, B * 512) && need(t->d256a, B * 256) &&
+          need(t->proba, B * 2) && need(t->d_loss, 64);
+    for (int b = 0; b < 4; ++b) {
+        dptm_trainer::Scratch& s = t->sc[b];
+        ok &= need(s.bnstat, 1024) && need(s.bnsums, 1024);
+        if (b == 3) break;
+        const size_t RM = (size_t)B * kW[b];
+        ok &= need(s.g64a, RM * 64) && need(s.g64b, RM * 64) && need(s.g64c, RM * 64) && need(s.g64d, RM * 64) &&
+              need(s.g256, RM * 256) && need(s.gq, RM * 64) && need(s.gk, RM * 64) && need(s.gv, RM * 64);
+    }
+    ok &= need(t->dconcat, B * 576) && need(t->d512a, B * 512) && need(t->d512b, B * 512) && need(t->d256a, B * 256) &&
           need(t->d256b, B * 256) && need(t->d128, B * 128);
     return ok ? DPTM_OK : tfail(DPTM_ENOMEM, "dptm_trainer_create: activation arena too small");
 }
@@ -187,8 +199,8 @@ size_t arena_bytes(int64_t B) {
         f += R * 64 * 9 + 2 * (R * 64 * 10 + R * 256 * 2 + R * 2 + (size_t)B * 4 * kW[b] * kW[b]) + R * 64 + R * 2;
     }
     f += (size_t)B * (128 * 2 + 512 * 3 + 256 + 576 + 512 * 3 + 256 * 3 + 2);
-    f += (size_t)B * 51 * (64 * 7 + 256) + (size_t)B * (576 + 1024 + 512 + 128);
-    return f * sizeof(float) + (size_t)512 * 256 + (1 << 20);   // + per-allocation rounding slack
+    f += (size_t)B * (21 + 33 + 51) * (64 * 7 + 256) + 8 * 1024 + (size_t)B * (576 + 1024 + 512 + 128);
+    return f * sizeof(float) + (size_t)640 * 256 + (1 << 20);   // + per-allocation rounding slack
 }
 
 struct Ctx {
@@ -196,17 +208,17 @@ struct Ctx {
     hipStream_t st;
     float* W;
     float* G;
+    dptm_trainer::Scratch* s;
     float* w(int id) const { return W + t->pm.t[id].off; }
     float* g(int id) const { return G + t->pm.t[id].off; }
 };
 
 // BatchNorm in training mode on y [rows][cols] -> z (may live inside a wider buffer)
 int bn_train_fwd(const Ctx& c, const float* y, float* z, int64_t ldz, int zoff, int64_t rows, int cols, const BnP& bn, float* mi) {
-    dptm_trainer* t = c.t;
-    T_TRY(hipMemsetAsync(t->bnstat, 0, 2 * cols * sizeof(float), c.st));
-    T_TRY(t_colsum2(y, nullptr, rows, cols, t->bnstat, c.st));
+    T_TRY(hipMemsetAsync(c.s->bnstat, 0, 2 * cols * sizeof(float), c.st));
+    T_TRY(t_colsum2(y, nullptr, rows, cols, c.s->bnstat, c.st));
     // the batch statistics ride in the (otherwise unused) moving-stat slots of the gradient buffer
-    T_TRY(t_bn_finalize(t->bnstat, cols, rows, mi, c.g(bn.mean), c.g(bn.var), c.st));
+    T_TRY(t_bn_finalize(c.s->bnstat, cols, rows, mi, c.g(bn.mean), c.g(bn.var), c.st));
     T_TRY(t_bn_fwd(y, z, rows, cols, mi, c.w(bn.gamma), c.w(bn.beta), ldz, zoff, c.st));
     return DPTM_OK;
 }
@@ -297,10 +309,10 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
     const int wl = a.wlen;
     const int64_t R = B * wl, R64 = R * 64;
     int rc;
-    float* dx = t->g64a;      // gradient w.r.t. the block output / running d(x)
-    float* dsum = t->g64b;
-    float* tmp = t->g64c;
-    float* dh = t->g64d;
+    float* dx = c.s->g64a;      // gradient w.r.t. the block output / running d(x)
+    float* dsum = c.s->g64b;
+    float* tmp = c.s->g64c;
+    float* dh = c.s->g64d;
     T_TRY(t_pool_bwd(a.xout, c.w(p.poolk), t->dconcat, kConcat, b * 64, a.pa, a.palpha, dx, c.g(p.poolk), c.g(p.poolb), B, wl, c.st));
     for (int i = 1; i >= 0; --i) {
         TbAct& q = a.tb[i];
@@ -311,34 +323,34 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
         T_TRY(hipMemcpyAsync(tmp, dsum, R64 * sizeof(float), hipMemcpyDeviceToDevice, c.st));
         T_TRY(t_dropout(tmp, R, 64, 64, 0, seed, b * 8 + 3 + 2 * i, rt.tb, c.st));
         T_TRY(t_gemm_tn(gt(q.u, 256, 0, tmp, 64, 0, c.g(w.f2k), 64, c.g(w.f2b), R, 256, 64), c.st));
-        T_TRY(t_gemm(ga(tmp, 64, c.w(w.f2k), 64, nullptr, t->g256, 256, 0, R, 64, 256), true, c.st));       // dU
-        T_TRY(t_swish_bwd(q.f1, t->g256, t->g256, R * 256, c.st));                                           // dF1
-        T_TRY(t_gemm_tn(gt(q.h, 64, 0, t->g256, 256, 0, c.g(w.f1k), 256, c.g(w.f1b), R, 64, 256), c.st));
+        T_TRY(t_gemm(ga(tmp, 64, c.w(w.f2k), 64, nullptr, c.s->g256, 256, 0, R, 64, 256), true, c.st));       // dU
+        T_TRY(t_swish_bwd(q.f1, c.s->g256, c.s->g256, R * 256, c.st));                                           // dF1
+        T_TRY(t_gemm_tn(gt(q.h, 64, 0, c.s->g256, 256, 0, c.g(w.f1k), 256, c.g(w.f1b), R, 64, 256), c.st));
         T_TRY(hipMemcpyAsync(dh, dsum, R64 * sizeof(float), hipMemcpyDeviceToDevice, c.st));                 // dH = dsum + ...
-        T_TRY(t_gemm(ga(t->g256, 256, c.w(w.f1k), 256, nullptr, dh, 64, 0, R, 256, 64, 0, 0, 1), true, c.st));
+        T_TRY(t_gemm(ga(c.s->g256, 256, c.w(w.f1k), 256, nullptr, dh, 64, 0, R, 256, 64, 0, 0, 1), true, c.st));
         // LayerNorm 1: dsum = d(x + ao)
         T_TRY(t_ln_bwd(dh, q.xh1, q.inv1, c.w(w.ln1g), dsum, c.g(w.ln1g), c.g(w.ln1b), R, c.st));
         T_TRY(hipMemcpyAsync(tmp, dsum, R64 * sizeof(float), hipMemcpyDeviceToDevice, c.st));
         T_TRY(t_dropout(tmp, R, 64, 64, 0, seed, b * 8 + 2 + 2 * i, rt.tb, c.st));                           // dAO
         T_TRY(t_gemm_tn(gt(q.o, 64, 0, tmp, 64, 0, c.g(w.wo), 64, c.g(w.bo), R, 64, 64), c.st));
         T_TRY(t_gemm(ga(tmp, 64, c.w(w.wo), 64, nullptr, dh, 64, 0, R, 64, 64), true, c.st));                // dO (in dh)
-        T_TRY(t_attn_bwd(q.q, q.k, q.v, q.prob, dh, t->gq, t->gk, t->gv, B, wl, c.st));
-        T_TRY(t_gemm_tn(gt(q.x, 64, 0, t->gq, 64, 0, c.g(w.wq), 64, c.g(w.bq), R, 64, 64), c.st));
-        T_TRY(t_gemm_tn(gt(q.x, 64, 0, t->gk, 64, 0, c.g(w.wk), 64, c.g(w.bk), R, 64, 64), c.st));
-        T_TRY(t_gemm_tn(gt(q.x, 64, 0, t->gv, 64, 0, c.g(w.wv), 64, c.g(w.bv), R, 64, 64), c.st));
+        T_TRY(t_attn_bwd(q.q, q.k, q.v, q.prob, dh, c.s->gq, c.s->gk, c.s->gv, B, wl, c.st));
+        T_TRY(t_gemm_tn(gt(q.x, 64, 0, c.s->gq, 64, 0, c.g(w.wq), 64, c.g(w.bq), R, 64, 64), c.st));
+        T_TRY(t_gemm_tn(gt(q.x, 64, 0, c.s->gk, 64, 0, c.g(w.wk), 64, c.g(w.bk), R, 64, 64), c.st));
+        T_TRY(t_gemm_tn(gt(q.x, 64, 0, c.s->gv, 64, 0, c.g(w.wv), 64, c.g(w.bv), R, 64, 64), c.st));
         // dX = dsum + dQ Wq^T + dK Wk^T + dV Wv^T   (written into dx)
         T_TRY(hipMemcpyAsync(dx, dsum, R64 * sizeof(float), hipMemcpyDeviceToDevice, c.st));
-        T_TRY(t_gemm(ga(t->gq, 64, c.w(w.wq), 64, nullptr, dx, 64, 0, R, 64, 64, 0, 0, 1), true, c.st));
-        T_TRY(t_gemm(ga(t->gk, 64, c.w(w.wk), 64, nullptr, dx, 64, 0, R, 64, 64, 0, 0, 1), true, c.st));
-        T_TRY(t_gemm(ga(t->gv, 64, c.w(w.wv), 64, nullptr, dx, 64, 0, R, 64, 64, 0, 0, 1), true, c.st));
+        T_TRY(t_gemm(ga(c.s->gq, 64, c.w(w.wq), 64, nullptr, dx, 64, 0, R, 64, 64, 0, 0, 1), true, c.st));
+        T_TRY(t_gemm(ga(c.s->gk, 64, c.w(w.wk), 64, nullptr, dx, 64, 0, R, 64, 64, 0, 0, 1), true, c.st));
+        T_TRY(t_gemm(ga(c.s->gv, 64, c.w(w.wv), 64, nullptr, dx, 64, 0, R, 64, 64, 0, 0, 1), true, c.st));
     }
     // conv block: x1 = BN2(swish(conv3b(z1))) + conv1(x0); dx = d(x1)
     // BatchNorm 2 -> dY2 (tmp) -> dA2 (tmp)
-    T_TRY(t_bn_bwd(dx, 64, 0, a.y2, tmp, R, 64, a.mi2, c.w(p.bn2.gamma), t->bnsums, c.g(p.bn2.gamma), c.g(p.bn2.beta), c.st));
+    T_TRY(t_bn_bwd(dx, 64, 0, a.y2, tmp, R, 64, a.mi2, c.w(p.bn2.gamma), c.s->bnsums, c.g(p.bn2.gamma), c.g(p.bn2.beta), c.st));
     T_TRY(t_swish_bwd(a.a2, tmp, tmp, R64, c.st));
     if ((rc = conv_bwd(c, a.z1, tmp, p.c3bk, p.c3bb, 3, dsum, false, R, wl))) return rc;     // dsum = dZ1 (after dropout)
     T_TRY(t_dropout(dsum, R, 64, 64, wl, seed, b * 8 + 1, rt.conv, c.st));
-    T_TRY(t_bn_bwd(dsum, 64, 0, a.y1, tmp, R, 64, a.mi1, c.w(p.bn1.gamma), t->bnsums, c.g(p.bn1.gamma), c.g(p.bn1.beta), c.st));
+    T_TRY(t_bn_bwd(dsum, 64, 0, a.y1, tmp, R, 64, a.mi1, c.w(p.bn1.gamma), c.s->bnsums, c.g(p.bn1.gamma), c.g(p.bn1.beta), c.st));
     T_TRY(t_swish_bwd(a.a1, tmp, tmp, R64, c.st));                                          // dA1
     if ((rc = conv_bwd(c, a.x0, tmp, p.c3ak, p.c3ab, 3, dh, false, R, wl))) return rc;       // dh = dX0 from conv3a
     if ((rc = conv_bwd(c, a.x0, dx, p.sck, p.scb, 1, dh, true, R, wl))) return rc;           // += shortcut path
@@ -359,6 +371,13 @@ void dptm_trainer_destroy(dptm_trainer* t) {
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     (void)hipDeviceSynchronize();
     if (t->gexec) (void)hipGraphExecDestroy(t->gexec);
+    for (int b = 0; b < 3; ++b)
+        if (t->aux[b]) (void)hipStreamDestroy(t->aux[b]);
+    for (int ph = 0; ph < 2; ++ph) {
+        if (t->ev_fork[ph]) (void)hipEventDestroy(t->ev_fork[ph]);
+        for (int b = 0; b < 3; ++b)
+            if (t->ev_join[ph][b]) (void)hipEventDestroy(t->ev_join[ph][b]);
+    }
     void* bufs[] = {t->W, t->G, t->M, t->V, t->trainable, t->arena.base, t->d_step};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
@@ -389,6 +408,13 @@ int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spe
     };
     if (hipSetDevice(device) != hipSuccess) return bail(DPTM_EINVAL, "dptm_trainer_create: no such device");
     if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) return bail(DPTM_EHIP, "hipStreamCreate failed");
+    for (int b = 0; b < 3; ++b)
+        if (hipStreamCreateWithFlags(&t->aux[b], hipStreamNonBlocking) != hipSuccess) return bail(DPTM_EHIP, "hipStreamCreate failed");
+    for (int ph = 0; ph < 2; ++ph) {
+        if (hipEventCreateWithFlags(&t->ev_fork[ph], hipEventDisableTiming) != hipSuccess) return bail(DPTM_EHIP, "hipEventCreate failed");
+        for (int b = 0; b < 3; ++b)
+            if (hipEventCreateWithFlags(&t->ev_join[ph][b], hipEventDisableTiming) != hipSuccess) return bail(DPTM_EHIP, "hipEventCreate failed");
+    }
     const size_t pb = (size_t)t->pm.total * sizeof(float);
     if (hipMalloc((void**)&t->W, pb) != hipSuccess || hipMalloc((void**)&t->G, pb) != hipSuccess ||
         hipMalloc((void**)&t->M, pb) != hipSuccess || hipMalloc((void**)&t->V, pb) != hipSuccess ||
@@ -433,7 +459,7 @@ int dptm_trainer_grad_buffer(dptm_trainer* t, float** dev_ptr, int64_t* count) {
 static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
                                     const float* strct, const float* esm, const int32_t* labels, int64_t n,
                                     const dptm_train_opts* o, hipStream_t st) {
-    Ctx c{t, st, t->W, t->G};
+    Ctx c{t, st, t->W, t->G, &t->sc[3]};
     const PMap& pm = t->pm;
     const Rates rt{o->rate_embed, o->rate_conv, o->rate_tb, o->rate_dense};
     const unsigned* seed = t->d_step;
@@ -442,9 +468,14 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
     int rc;
     T_TRY(hipMemsetAsync(t->G, 0, (size_t)pm.total * sizeof(float), st));
     T_TRY(hipMemsetAsync(t->d_loss, 0, 64 * sizeof(float), st));
-    // ---------------- forward
-    for (int b = 0; b < 3; ++b)
-        if ((rc = branch_fwd(c, b, tok[b], B, seed, rt))) return rc;
+    // ---------------- forward: the three sequence branches on side streams, the per-site layers on `st`
+    T_TRY(hipEventRecord(t->ev_fork[0], st));
+    for (int b = 0; b < 3; ++b) {
+        T_TRY(hipStreamWaitEvent(t->aux[b], t->ev_fork[0], 0));
+        Ctx cb{t, t->aux[b], t->W, t->G, &t->sc[b]};
+        if ((rc = branch_fwd(cb, b, tok[b], B, seed, rt))) return rc;
+        T_TRY(hipEventRecord(t->ev_join[0][b], t->aux[b]));
+    }
     // struct branch (model.py:187-189)
     T_TRY(t_gemm(ga(strct, 8, c.w(pm.strct.k), 128, c.w(pm.strct.b), t->sa, 128, 0, B, 8, 128), false, st));
     T_TRY(t_swish_fwd(t->sa, t->sy, B * 128, st));
@@ -460,6 +491,7 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
         T_TRY(t_swish_fwd(t->e2a, t->d256a, B * 256, st));
         T_TRY(t_copy_cols(t->concat, kConcat, 320, t->d256a, 256, 0, B, 256, false, st));
     }
+    for (int b = 0; b < 3; ++b) T_TRY(hipStreamWaitEvent(st, t->ev_join[0][b], 0));   // pooled branch outputs are in concat
     T_TRY(t_dropout(t->concat, B, kConcat, kConcat, 0, seed, 24 + 2, rt.dense, st));
     // trunk (model.py:200-205)
     T_TRY(t_gemm(ga(t->concat, kConcat, c.w(pm.t1.k), 512, c.w(pm.t1.b), t->t1a, 512, 0, B, kConcat, 512), false, st));
@@ -474,12 +506,12 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
                       c.g(pm.head.k), c.g(pm.head.b), st));
     // ---------------- backward, per-site layers
     // trunk 2: BN -> swish -> dense
-    T_TRY(t_bn_bwd(t->d256a, 256, 0, t->t2y, t->d256b, B, 256, t->t2mi, c.w(pm.t2.bn.gamma), t->bnsums, c.g(pm.t2.bn.gamma), c.g(pm.t2.bn.beta), st));
+    T_TRY(t_bn_bwd(t->d256a, 256, 0, t->t2y, t->d256b, B, 256, t->t2mi, c.w(pm.t2.bn.gamma), c.s->bnsums, c.g(pm.t2.bn.gamma), c.g(pm.t2.bn.beta), st));
     T_TRY(t_swish_bwd(t->t2a, t->d256b, t->d256b, B * 256, st));
     T_TRY(t_gemm_tn(gt(t->t1z, 512, 0, t->d256b, 256, 0, c.g(pm.t2.k), 256, c.g(pm.t2.b), B, 512, 256), st));
     T_TRY(t_gemm(ga(t->d256b, 256, c.w(pm.t2.k), 256, nullptr, t->d512a, 512, 0, B, 256, 512), true, st));
     T_TRY(t_dropout(t->d512a, B, 512, 512, 0, seed, 24 + 3, rt.dense, st));
-    T_TRY(t_bn_bwd(t->d512a, 512, 0, t->t1y, t->d512b, B, 512, t->t1mi, c.w(pm.t1.bn.gamma), t->bnsums, c.g(pm.t1.bn.gamma), c.g(pm.t1.bn.beta), st));
+    T_TRY(t_bn_bwd(t->d512a, 512, 0, t->t1y, t->d512b, B, 512, t->t1mi, c.w(pm.t1.bn.gamma), c.s->bnsums, c.g(pm.t1.bn.gamma), c.g(pm.t1.bn.beta), st));
     T_TRY(t_swish_bwd(t->t1a, t->d512b, t->d512b, B * 512, st));
     T_TRY(t_gemm_tn(gt(t->concat, kConcat, 0, t->d512b, 512, 0, c.g(pm.t1.k), 512, c.g(pm.t1.b), B, kConcat, 512), st));
     T_TRY(t_gemm(ga(t->d512b, 512, c.w(pm.t1.k), 512, nullptr, t->dconcat, kConcat, 0, B, 512, kConcat), true, st));
@@ -490,18 +522,24 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
     T_TRY(t_gemm_tn(gt(t->e1, 512, 0, t->d256a, 256, 0, c.g(pm.esm2.k), 256, c.g(pm.esm2.b), B, 512, 256), st));
     T_TRY(t_gemm(ga(t->d256a, 256, c.w(pm.esm2.k), 256, nullptr, t->d512a, 512, 0, B, 256, 512), true, st));
     T_TRY(t_dropout(t->d512a, B, 512, 512, 0, seed, 24 + 1, rt.dense, st));
-    T_TRY(t_bn_bwd(t->d512a, 512, 0, t->ey, t->d512b, B, 512, t->emi, c.w(pm.esm1.bn.gamma), t->bnsums, c.g(pm.esm1.bn.gamma), c.g(pm.esm1.bn.beta), st));
+    T_TRY(t_bn_bwd(t->d512a, 512, 0, t->ey, t->d512b, B, 512, t->emi, c.w(pm.esm1.bn.gamma), c.s->bnsums, c.g(pm.esm1.bn.gamma), c.g(pm.esm1.bn.beta), st));
     T_TRY(t_swish_bwd(t->ea, t->d512b, t->d512b, B * 512, st));
     T_TRY(t_gemm_tn(gt(esm, kEsm, 0, t->d512b, 512, 0, c.g(pm.esm1.k), 512, c.g(pm.esm1.b), B, kEsm, 512), st));
     // struct branch: d(concat[:,192:320]) -> dropout -> BN -> swish -> dense
     T_TRY(t_copy_cols(t->d128, 128, 0, t->dconcat, kConcat, 192, B, 128, false, st));
     T_TRY(t_dropout(t->d128, B, 128, 128, 0, seed, 24 + 0, rt.dense, st));
-    T_TRY(t_bn_bwd(t->d128, 128, 0, t->sy, t->d512a, B, 128, t->smi, c.w(pm.strct.bn.gamma), t->bnsums, c.g(pm.strct.bn.gamma), c.g(pm.strct.bn.beta), st));
+    T_TRY(t_bn_bwd(t->d128, 128, 0, t->sy, t->d512a, B, 128, t->smi, c.w(pm.strct.bn.gamma), c.s->bnsums, c.g(pm.strct.bn.gamma), c.g(pm.strct.bn.beta), st));
     T_TRY(t_swish_bwd(t->sa, t->d512a, t->d512a, B * 128, st));
     T_TRY(t_gemm_tn(gt(strct, 8, 0, t->d512a, 128, 0, c.g(pm.strct.k), 128, c.g(pm.strct.b), B, 8, 128), st));
-    // sequence branches
-    for (int b = 0; b < 3; ++b)
-        if ((rc = branch_bwd(c, b, tok[b], B, seed, rt))) return rc;
+    // sequence branches, again side by side (d(concat) is complete; each branch owns its parameters' gradients)
+    T_TRY(hipEventRecord(t->ev_fork[1], st));
+    for (int b = 0; b < 3; ++b) {
+        T_TRY(hipStreamWaitEvent(t->aux[b], t->ev_fork[1], 0));
+        Ctx cb{t, t->aux[b], t->W, t->G, &t->sc[b]};
+        if ((rc = branch_bwd(cb, b, tok[b], B, seed, rt))) return rc;
+        T_TRY(hipEventRecord(t->ev_join[1][b], t->aux[b]));
+    }
+    for (int b = 0; b < 3; ++b) T_TRY(hipStreamWaitEvent(st, t->ev_join[1][b], 0));
     // l2 kernel regularisers (model.py:130-138,200,204): value into the loss, 2*lambda*w into the gradient
     if (o->l2 > 0.f)
         for (const Tn& x : pm.t)
@@ -509,9 +547,10 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
     return DPTM_OK;
 }
 
-// Forward in training mode + loss + backward for one local batch (device pointers).  The launch sequence
-// (about 300 small kernels) is captured into a graph the second time a call repeats the previous call's
-// batch size, buffers, dropout rates, l2 and stream, and replayed from then on; DPTM_TRAIN_GRAPH=0 disables it.
+// Forward in training mode + loss + backward for one local batch (device pointers).  With
+// DPTM_TRAIN_GRAPH=1 the launch sequence (about 300 small kernels over four streams) is captured into a
+// graph the second time a call repeats the previous call's batch size, buffers, dropout rates, l2 and
+// stream, and replayed from then on.  Off by default: on this stack eager issue is the faster of the two.
 int dptm_trainer_forward_backward(dptm_trainer* t, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
                                   const float* strct, const float* esm, const int32_t* labels, int64_t n,
                                   const dptm_train_opts* o, float* loss_out, void* stream) {
