@@ -141,15 +141,20 @@ def train_main(args) -> None:
     o = _native.TrainOpts()
     o.rate_embed, o.rate_conv, o.rate_tb, o.rate_dense = 1e-4, 0.3, 0.1, 0.3
     o.n_global, o.n_pos_global, o.l2, o.l2_scale = b * world, int(n_pos.item()), 1e-4, 1.0 / world
-    st = torch.cuda.current_stream().cuda_stream
+    # one explicit stream for the whole step: the library's kernels, RCCL's all-reduce (which orders itself
+    # after torch's current stream) and the optimizer update are then stream-ordered without host syncs
+    tstream = torch.cuda.Stream(device=dev)
+    st = tstream.cuda_stream
+    torch.cuda.synchronize()
 
     def step(i):
         o.seed = i * 1000003 + rank
-        backend.trainer.forward_backward(x[0].data_ptr(), x[1].data_ptr(), x[2].data_ptr(), x[3].data_ptr(),
-                                         x[4].data_ptr(), labels.data_ptr(), b, o, False, st)
-        if dist is not None:
-            backend.allreduce_grads()
-        backend.trainer.apply(5e-4, 1e-4, 1.0, 1.0 / world, st)
+        with torch.cuda.stream(tstream):
+            backend.trainer.forward_backward(x[0].data_ptr(), x[1].data_ptr(), x[2].data_ptr(), x[3].data_ptr(),
+                                             x[4].data_ptr(), labels.data_ptr(), b, o, False, st)
+            if dist is not None:
+                backend.allreduce_grads()
+            backend.trainer.apply(5e-4, 1e-4, 1.0, 1.0 / world, st)
 
     def barrier():
         torch.cuda.synchronize()
