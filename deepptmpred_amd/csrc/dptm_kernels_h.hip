@@ -37,6 +37,18 @@ struct Frag {                    // one MFMA operand: 8 k-elements per lane (hi,
     typename HP<MODE>::frag hi, lo;
 };
 
+// x - (float)half, the half taken from the low / high 16 bits of a packed pair: one mixed-precision FMA
+// (v_fma_mix_f32 reads the f16 operand directly) instead of a conversion and a subtraction
+template <int HIGH>
+__device__ __forceinline__ float sub_half(float x, unsigned pair) {
+    float d;
+    if (HIGH)
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pair), "v"(x));
+    else
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pair), "v"(x));
+    return d;
+}
+
 // 8 fp32 values (two chain-layout groups) -> operand fragment
 template <int MODE>
 __device__ __forceinline__ Frag<MODE> make_frag(const f32x4& x0, const f32x4& x1) {
@@ -48,10 +60,14 @@ __device__ __forceinline__ Frag<MODE> make_frag(const f32x4& x0, const f32x4& x1
         f.hi[4 + e] = (E)x1[e];
     }
     if (HP<MODE>::kSplit) {
+        const uint4 hp = __builtin_bit_cast(uint4, f.hi);
+        const unsigned pr[4] = {hp.x, hp.y, hp.z, hp.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            f.lo[e] = (E)(x0[e] - (float)f.hi[e]);
-            f.lo[4 + e] = (E)(x1[e] - (float)f.hi[4 + e]);
+        for (int q = 0; q < 2; ++q) {
+            f.lo[2 * q] = (E)sub_half<0>(x0[2 * q], pr[q]);
+            f.lo[2 * q + 1] = (E)sub_half<1>(x0[2 * q + 1], pr[q]);
+            f.lo[4 + 2 * q] = (E)sub_half<0>(x1[2 * q], pr[2 + q]);
+            f.lo[5 + 2 * q] = (E)sub_half<1>(x1[2 * q + 1], pr[2 + q]);
         }
     }
     return f;
@@ -415,7 +431,9 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
                         const float v = acc[t][r];
                         const E vh = (E)v;
                         *reinterpret_cast<E*>(vb + feat * kVtRowB) = vh;
-                        if (HP<MODE>::kSplit) *reinterpret_cast<E*>(vb + kVtLoOff + feat * kVtRowB) = (E)(v - (float)vh);
+                        if (HP<MODE>::kSplit)
+                            *reinterpret_cast<E*>(vb + kVtLoOff + feat * kVtRowB) =
+                                (E)sub_half<0>(v, (unsigned)__builtin_bit_cast(unsigned short, vh));
                     }
             } else {
                 f32x4 qx[4 * NTQ];
