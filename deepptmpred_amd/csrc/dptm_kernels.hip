@@ -459,25 +459,25 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
 #pragma unroll
             for (int e = 0; e < 4; ++e) part = fmaf(x1[u][e], wv[e], part);
         }
-        const float sc = tanhf(xhalf_sum(part) + vecs[kVecsPool + kVec64][0]);
+        // the score is a tanh, so it lies in [-1, 1]: softmax needs no running maximum, and every row computes
+        // its own exponential once; the per-site sum and the weighted sum over positions follow from LDS
+        const float ew = __expf(tanhf(xhalf_sum(part) + vecs[kVecsPool + kVec64][0]));
         __syncthreads();  // all attention reads of bufA are finished
         float* xb = bufA + row * kLdsStride + 4 * h;
 #pragma unroll
         for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x4*>(xb + 8 * u) = x1[u];
-        if (h == 0) score[row] = sc;
+        if (h == 0) score[row] = ew;
         __syncthreads();
-        for (int o = tid; o < sites_here * 64; o += 512) {
-            const int s = o >> 6, f = o & 63;
+        for (int oi = tid; oi < sites_here * 64; oi += 512) {
+            const int s = oi >> 6, f = oi & 63;
             const float* sp = score + s * W;
-            float m = sp[0];
-#pragma unroll
-            for (int t = 1; t < W; ++t) m = fmaxf(m, sp[t]);
+            const float* xp = bufA + (s * W) * kLdsStride + f;
             float den = 0.f, acc = 0.f;
 #pragma unroll
             for (int t = 0; t < W; ++t) {
-                const float e = __expf(sp[t] - m);
+                const float e = sp[t];
                 den += e;
-                acc = fmaf(e, bufA[(s * W + t) * kLdsStride + f], acc);
+                acc = fmaf(e, xp[t * kLdsStride], acc);
             }
             out[(site0 + s) * ldo + col_off + f] = acc / den;
         }

@@ -19,6 +19,19 @@
 
 namespace dptm {
 
+#ifdef DPTM_PHASE_TIMING
+// Debug build only: cycles per phase summed over all wavefronts (phase ids in PH_MARK calls), read back with
+// dptm_debug_phase_cycles().  s_memtime is a read of the clock; the sums go out through vector atomics.
+__device__ unsigned long long g_phase_cycles[16];
+#define PH_DECL unsigned long long ph_t0 = __builtin_amdgcn_s_memtime(); unsigned long long ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PH_MARK(id) { const unsigned long long ph_t1 = __builtin_amdgcn_s_memtime(); ph_acc[id] += ph_t1 - ph_t0; ph_t0 = ph_t1; }
+#define PH_FLUSH if ((threadIdx.x & 63) == 0) { for (int ph_i = 0; ph_i < 12; ++ph_i) atomicAdd(&g_phase_cycles[ph_i], ph_acc[ph_i]); }
+#else
+#define PH_DECL
+#define PH_MARK(id)
+#define PH_FLUSH
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -243,6 +256,14 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31;
+    PH_DECL
+    for (int i = tid; i < kVecsF4; i += 512) vecs[i] = P[vecs_source(i)];
+    if (tid < (S + 1) * 2) {
+        typename HP<MODE>::frag f;
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) f[idx] = (8 * (tid & 1) + idx == (tid >> 1)) ? (E)1.0f : (E)0.0f;
+        site_frag[tid] = as_u4<MODE>(f);
+    }
     const int64_t site0 = (int64_t)blockIdx.x * S;
     const int sites_here = (int)min((int64_t)S, n_sites - site0);
     const int rows_valid = sites_here * W;
@@ -285,25 +306,22 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
 #pragma unroll
         for (int idx = 0; idx < 8; ++idx) qsite[idx] = (8 * h + idx == qs) ? (E)0.0f : (E)(-60000.0f);
     }
-    if (tid < (S + 1) * 2) {
-        typename HP<MODE>::frag f;
-#pragma unroll
-        for (int idx = 0; idx < 8; ++idx) f[idx] = (8 * (tid & 1) + idx == (tid >> 1)) ? (E)1.0f : (E)0.0f;
-        site_frag[tid] = as_u4<MODE>(f);
-    }
 
-    for (int i = threadIdx.x; i < kVecsF4; i += 512) vecs[i] = P[vecs_source(i)];
     // ---- embedding + position embedding, this lane's row in the chain layout (model.py:157-158)
+    // Both tables (21 + W rows of 64 floats) are first copied into the still unused second LDS region: a
+    // per-lane gather from memory touches up to 64 cache lines per instruction and dominated the prologue.
+    f32x4* tabs = reinterpret_cast<f32x4*>(regB);
+    for (int i = tid; i < (kCodes + W) * 16; i += 512) tabs[i] = P[kOffEmb + i];     // kOffPos == kOffEmb + 21*16
+    static_assert(kOffPos == kOffEmb + kCodes * 16, "embedding and position tables must be adjacent");
+    int tk = row_ok ? tok[site0 * W + row] : 0;
+    tk = tk > kCodes - 1 ? kCodes - 1 : tk;
+    __syncthreads();
     f32x4 x1[8];
-    {
-        int t = row_ok ? tok[(site0 + site_l) * W + pos_l] : 0;
-        t = t > kCodes - 1 ? kCodes - 1 : t;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row_ok) v = P[kOffEmb + t * 16 + 2 * u + h] + P[kOffPos + pos_l * 16 + 2 * u + h];
-            x1[u] = v;
-        }
+    for (int u = 0; u < 8; ++u) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row_ok) v = tabs[tk * 16 + 2 * u + h] + tabs[(kCodes + pos_l) * 16 + 2 * u + h];
+        x1[u] = v;
     }
     Frag<MODE> fx[4];
 #pragma unroll
@@ -311,7 +329,9 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
         fx[ks] = make_frag<MODE>(x1[2 * ks], x1[2 * ks + 1]);
         store_frag<MODE>(regA, row, ks, h, fx[ks]);
     }
+    PH_MARK(9)    // set-up, embedding
     __syncthreads();
+    PH_MARK(10)   // barrier wait
 
     // ---- residual conv block (model.py:129-141)
     {
@@ -348,6 +368,7 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
             fy[ks] = make_frag<MODE>(y[2 * ks], y[2 * ks + 1]);
             store_frag<MODE>(regB, row, ks, h, fy[ks]);
         }
+        PH_MARK(11)   // shortcut + first conv, activation
         __syncthreads();
         f32x16 acc_b[2];
         acc_bias<2>(acc_b, cv + kVC3bB * kVec64, h, 8);
@@ -375,6 +396,7 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
         }
     }
 
+    PH_MARK(0)   // barrier + second conv, activation, residual
     // ---- two transformer blocks (model.py:93-118, 172-173)
     // Weight fragments travel through two register buffers (wa, wb) that are refilled one
     // layer ahead of their use, so the L2 latency of a layer's weights hides behind the
@@ -394,7 +416,9 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
         wq[0].load(Thi + kTbWk / 2, Tlo + kTbWk / 2, 4, 0, 0, lane);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fx[ks] = make_frag<MODE>(x1[2 * ks], x1[2 * ks + 1]);
+        PH_MARK(1)   // fragments of x1, first weight loads
         __syncthreads();   // every wave is done with regA/regB (conv taps, or the previous block's K / V^T)
+        PH_MARK(2)   // barrier wait
         Frag<MODE> fq[4];   // Q operand per head, scaled by log2(e)/sqrt(16): the softmax below works in base 2
 #pragma unroll
         for (int u = 0; u < 3 * NP; ++u) {
@@ -443,7 +467,9 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
                 for (int hd = 0; hd < 2 * NTQ; ++hd) fq[2 * t0 + hd] = make_frag<MODE>(qx[2 * hd] * kQScale, qx[2 * hd + 1] * kQScale);
             }
         }
+        PH_MARK(3)   // K, V, Q projections and their LDS images
         __syncthreads();   // K and V^T of the whole tile are in LDS
+        PH_MARK(4)   // barrier wait
 
         // attention, one head at a time, keys walked in aligned 32-key tiles with a running maximum
         f32x4 o[8];        // attention output of this lane's row, chain layout
@@ -501,6 +527,7 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
             }
         }
 
+        PH_MARK(5)   // attention
         // output projection, residual, LayerNorm 1
         // FFN 64 -> 256 (swish) -> 64 walks the hidden units in chunks of HT 32-wide tiles (one tile in the
         // split mode, whose fragments are twice as large), residual, LayerNorm 2
@@ -527,6 +554,7 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
             for (int u = 0; u < 8; ++u) hres[u] += x1[u];
             layernorm64_h(hres, tv + kVLn1G * kVec64, tv + kVLn1B * kVec64, h);
         }
+        PH_MARK(6)   // output projection, LayerNorm 1
         {
             Frag<MODE> fh[4];
 #pragma unroll
@@ -561,6 +589,7 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
             for (int u = 0; u < 8; ++u) x1[u] += hres[u];
             layernorm64_h(x1, tv + kVLn2G * kVec64, tv + kVLn2B * kVec64, h);
         }
+        PH_MARK(7)   // FFN, LayerNorm 2
     }
 
     // ---- attention pooling (model.py:176-182), fp32 on the vector units
@@ -572,30 +601,32 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
 #pragma unroll
             for (int e = 0; e < 4; ++e) part = fmaf(x1[u][e], wv[e], part);
         }
-        const float sc = tanhf(xhalf_sum_h(part) + vecs[kVecsPool + kVec64][0]);
+        // the score is a tanh, so it lies in [-1, 1]: softmax needs no running maximum, and every row computes
+        // its own exponential once; the per-site sum and the weighted sum over positions follow from LDS
+        const float ew = __expf(tanhf(xhalf_sum_h(part) + vecs[kVecsPool + kVec64][0]));
         __syncthreads();   // all attention reads of regA are finished
         float* bufX = reinterpret_cast<float*>(regA);
         float* xb = bufX + row * kLdsStride + 4 * h;
 #pragma unroll
         for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x4*>(xb + 8 * u) = x1[u];
-        if (h == 0) score[row] = sc;
+        if (h == 0) score[row] = ew;
         __syncthreads();
         for (int oi = tid; oi < sites_here * 64; oi += 512) {
             const int s = oi >> 6, f = oi & 63;
             const float* sp = score + s * W;
-            float m = sp[0];
-#pragma unroll
-            for (int t = 1; t < W; ++t) m = fmaxf(m, sp[t]);
+            const float* xp = bufX + (s * W) * kLdsStride + f;
             float den = 0.f, acc = 0.f;
 #pragma unroll
             for (int t = 0; t < W; ++t) {
-                const float e = __expf(sp[t] - m);
+                const float e = sp[t];
                 den += e;
-                acc = fmaf(e, bufX[(s * W + t) * kLdsStride + f], acc);
+                acc = fmaf(e, xp[t * kLdsStride], acc);
             }
             out[(site0 + s) * ldo + col_off + f] = acc / den;
         }
     }
+    PH_MARK(8)   // pooling
+    PH_FLUSH
 }
 
 // ------------------------------------------------------------------------------------
@@ -770,5 +801,16 @@ hipError_t launch_branch_h(int mode, int w, const float* params, const void* whi
         default: return hipErrorInvalidValue;
     }
 }
+
+#ifdef DPTM_PHASE_TIMING
+extern "C" int dptm_debug_phase_cycles(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 }  // namespace dptm
