@@ -158,23 +158,60 @@ class Model:
 
     def fit(self, x, y, batch_size: int = 64, epochs: int = 1, validation_data=None, callbacks=None,
             verbose=1, shuffle: bool = True, **_ignored):
-        """``model.fit`` (trainer.py:332-339).  Of the reference's callbacks only a learning-rate
-        schedule is honoured: any callback object with a ``schedule(epoch, lr)`` attribute
-        (keras ``LearningRateScheduler``) or a plain callable."""
-        sched = None
+        """``model.fit`` as trainer.py:330-339 calls it: one pass over the data per epoch through the
+        native training step, then -- with ``validation_data`` -- ``val_loss`` (data term of the loss +
+        the l2 regularisers), ``val_accuracy`` and ``val_auc`` from the scoring path, then the callbacks
+        (``deepptmpred_amd.callbacks``: LearningRateScheduler, EarlyStopping, ModelCheckpoint, CSVLogger;
+        a plain ``schedule(epoch, lr)`` callable is taken as a learning-rate schedule).  Returns a
+        ``History`` (``.history['loss']`` ...)."""
+        from .callbacks import Callback, History, LearningRateScheduler, balanced_bce, roc_auc
+        from .training import labels_from_targets
+        cbs = []
         for cb in callbacks or []:
-            if callable(getattr(cb, "schedule", None)):
-                sched = cb.schedule
+            if isinstance(cb, Callback):
+                cbs.append(cb)
+            elif callable(getattr(cb, "schedule", None)):
+                cbs.append(LearningRateScheduler(cb.schedule))
             elif callable(cb):
-                sched = cb
-        hist = self._trainer(batch_size).fit(x, y, batch_size, epochs, shuffle, sched, verbose=int(bool(verbose)))
-        self._dirty = True
-        if validation_data is not None:
-            vx, vy = validation_data
-            p = self.predict(vx)
-            hist["val_accuracy"] = [float(np.mean(np.argmax(p, axis=1) == np.argmax(np.asarray(vy), axis=-1)
-                                                  if np.asarray(vy).ndim == 2 else np.argmax(p, axis=1) == np.asarray(vy)))]
+                cbs.append(LearningRateScheduler(cb))
+        for cb in cbs:
+            cb.set_model(self)
+            cb.on_train_begin()
+        trainer = self._trainer(batch_size)
+        hist = History()
+        lr = trainer.optimizer.learning_rate
+        for epoch in range(int(epochs)):
+            for cb in cbs:
+                lr = cb.on_epoch_begin(epoch, lr)
+            trainer = self._trainer(batch_size)       # a callback may have replaced the weights
+            h1 = trainer.fit(x, y, batch_size, 1, shuffle, lambda _e, _lr, _v=lr: _v, seed=epoch, verbose=0)
+            self._dirty = True
+            logs = {"loss": h1["loss"][0], "lr": lr}
+            if validation_data is not None:
+                vx, vy = validation_data
+                vl = labels_from_targets(vy)
+                p = self.predict(vx)
+                reg = sum(float(self.spec.weight_decay) * float(np.sum(np.square(self._weights[n].astype(np.float64))))
+                          for n in self._l2_names())
+                logs["val_loss"] = balanced_bce(p, vl) + reg
+                logs["val_accuracy"] = float(np.mean(np.argmax(p, axis=1) == vl))
+                logs["val_auc"] = roc_auc(vl, p[:, 1])
+            for k, v in logs.items():
+                hist.setdefault(k, []).append(v)
+            if verbose:
+                print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4g" % kv for kv in logs.items()))
+            for cb in cbs:
+                cb.on_epoch_end(epoch, logs)
+            if any(cb.stop_training for cb in cbs):
+                break
+        for cb in cbs:
+            cb.on_train_end()
         return hist
+
+    def _l2_names(self) -> List[str]:
+        """Kernels that carry the l2(weight_decay) regulariser (model.py:130-138, 200, 204)."""
+        return [n for n, _ in tensor_table(self.spec)
+                if n.endswith((".sc_k", ".c3a_k", ".c3b_k")) or n in ("t1.k", "t2.k")]
 
     def get_weights(self) -> List[np.ndarray]:
         if getattr(self, "_dirty", False):
@@ -195,6 +232,12 @@ class Model:
         self._weights = new
         self._blob = pack_blob(new, self.spec)
         self.close()
+        # a live trainer still holds the old weights (and their Adam moments): drop it, the next training
+        # call starts a fresh one from the weights just set
+        if getattr(self, "_dp", None) is not None:
+            self._dp.backend.close()
+            self._dp = None
+        self._dirty = False
 
     def named_weights(self) -> Dict[str, np.ndarray]:
         return dict(self._weights)

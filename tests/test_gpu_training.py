@@ -109,3 +109,41 @@ def test_keras_like_fit_reduces_loss_and_updates_predictions():
     ws = m.get_weights()
     assert all(np.isfinite(w).all() for w in ws)
     m.close()
+
+
+def test_fit_with_validation_and_reference_callbacks(tmp_path):
+    """The callback set of trainer.py:311-328 around the native step: validation metrics per epoch,
+    early stopping on val_auc with the best weights put back, best-only checkpoints, a CSV log."""
+    from deepptmpred_amd.callbacks import CSVLogger, EarlyStopping, LearningRateScheduler, ModelCheckpoint, TensorBoard
+    from deepptmpred_amd.model import create_ptm_model, load_model
+    from deepptmpred_amd.training import AdamW, lr_schedule
+    from oracle.train_ref import TrainRef
+    m = create_ptm_model(seed=5)
+    x = spec.synthetic_inputs(320, 78)
+    y = (x[3][:, 0] > 125).astype(np.int64)
+    tr = [a[:256] for a in x]
+    va = [a[256:] for a in x]
+    m.compile(optimizer=AdamW(learning_rate=5e-4, weight_decay=1e-4), loss=None, metrics=["accuracy"])
+    ck = ModelCheckpoint(str(tmp_path / "best_model.h5"), monitor="val_auc", save_best_only=True, mode="max")
+    es = EarlyStopping(monitor="val_auc", patience=3, min_delta=0.01, mode="max", restore_best_weights=True)
+    hist = m.fit(tr, np.eye(2)[y[:256]], batch_size=64, epochs=8, validation_data=(va, np.eye(2)[y[256:]]), verbose=0,
+                 callbacks=[LearningRateScheduler(lr_schedule), es, ck, CSVLogger(str(tmp_path / "log.csv")),
+                            TensorBoard(log_dir=str(tmp_path / "tb"))])
+    n_ep = len(hist.history["loss"])
+    assert 1 <= n_ep <= 8 and set(hist) >= {"loss", "lr", "val_loss", "val_accuracy", "val_auc"}
+    assert hist["lr"][0] == pytest.approx(1e-4) and all(0.0 <= a <= 1.0 for a in hist["val_auc"])
+    assert len(open(tmp_path / "log.csv").read().strip().splitlines()) == n_ep + 1
+    # the checkpoint holds the best epoch's weights and loads back through the Keras-HDF5 reader
+    assert ck.saved_epochs and ck.saved_epochs[-1] == int(np.argmax(hist["val_auc"]))
+    best = load_model(str(tmp_path / "best_model.h5"))
+    p_best = best.predict(va)
+    # val_loss is the oracle's loss (data term + l2) of the weights at that epoch
+    if ck.saved_epochs[-1] == n_ep - 1 or es.stop_training:
+        ref = TrainRef(best.named_weights())
+        import torch
+        want = float(ref.loss(torch.as_tensor(p_best, dtype=torch.float64), y[256:]).detach())
+        assert hist["val_loss"][ck.saved_epochs[-1]] == pytest.approx(want, rel=1e-4)
+    if es.stop_training:        # restore_best_weights: the model scores like the checkpoint
+        assert np.abs(m.predict(va) - p_best).max() < 1e-6
+    best.close()
+    m.close()
