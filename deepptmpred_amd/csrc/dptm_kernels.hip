@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dptm_layout.h"
+#include "dptm_phase.h"
 #include "dptm_kernels.h"
 
 namespace dptm {
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
     const int sites_here = (int)min((int64_t)S, n_sites - site0);
     const int rows_valid = sites_here * W;
 
+    PH_DECL
     for (int i = tid; i < kVecsF4; i += 512) vecs[i] = P[vecs_source(i)];
     // ---- embedding + position embedding -> bufA   (model.py:157-158)
     for (int idx = tid; idx < kTileRows * 16; idx += 512) {
@@ -179,6 +181,7 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
     const bool tap0_ok = row_ok && pos_l > 0;
     const bool tap2_ok = row_ok && pos_l < W - 1;
 
+    PH_MARK(9)    // set-up, embedding (incl. its barrier)
     f32x4 x1[8];  // residual stream of this lane's row, chain layout
 
     // ---- residual conv block (model.py:129-141)
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
         }
     }
 
+    PH_MARK(0)    // conv block
     // ---- two transformer blocks (model.py:93-118, 172-173)
 #pragma unroll 1
     for (int blk = 0; blk < 2; ++blk) {
@@ -289,6 +293,7 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
         const f32x4* tv = vecs + kVecsConv + blk * kVecsTb;
         // every wave is done reading bufA/bufB (conv taps, or the previous block's K/V)
         __syncthreads();
+        PH_MARK(2)   // barrier wait
         {
             f32x16 acc[2];
             acc_init_bias<2>(acc, tv + kVBk * kVec64, h, 8);
@@ -324,7 +329,9 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
                 half_swap(qa[r], qb[r]);
             }
         }
+        PH_MARK(3)   // K, V, Q projections
         __syncthreads();  // K and V of the whole tile are in LDS
+        PH_MARK(4)   // barrier wait
         // attention: this lane = (query row, two heads).  After the regrouping,
         // qa[4u+e] / qb[4u+e] hold features 32h + 8u + e / 32h + 8u + 4 + e.
         // Keys are walked in three chunks of W/3 with a running maximum (the usual
@@ -387,6 +394,7 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
                 qb[8 * hd + 4 + e] = o3[e] * rden;
             }
         }
+        PH_MARK(5)   // attention
         // back to the chain layout, output projection, residual, LayerNorm 1
         f32x4 hres[8];
         {
@@ -405,7 +413,8 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
             for (int u = 0; u < 8; ++u) hres[u] += x1[u];
             layernorm64(hres, tv + kVLn1G * kVec64, tv + kVLn1B * kVec64, h);
         }
-        // FFN 64 -> 256 (swish) -> 64 in two hidden halves of 128, residual, LayerNorm 2
+        PH_MARK(6)   // output projection, LayerNorm 1
+        // FFN 64 -> 256 (swish) -> 64 in four hidden chunks of 64, residual, LayerNorm 2
         {
             f32x16 acc_o[2];
             acc_init_bias<2>(acc_o, tv + kVB2 * kVec64, h, 8);
@@ -448,6 +457,7 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
             for (int u = 0; u < 8; ++u) x1[u] += hres[u];
             layernorm64(x1, tv + kVLn2G * kVec64, tv + kVLn2B * kVec64, h);
         }
+        PH_MARK(7)   // FFN, LayerNorm 2
     }
 
     // ---- attention pooling (model.py:176-182)
@@ -482,6 +492,8 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
             out[(site0 + s) * ldo + col_off + f] = acc / den;
         }
     }
+    PH_MARK(8)   // pooling
+    PH_FLUSH
 }
 
 // ------------------------------------------------------------------------------------
@@ -778,3 +790,5 @@ hipError_t launch_assemble(const uint8_t* codes, int64_t L, int64_t esm_rows,
 }
 
 }  // namespace dptm
+
+PH_DEFINE_READER(dptm_debug_phase_cycles_f32)

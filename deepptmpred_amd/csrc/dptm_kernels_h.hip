@@ -16,21 +16,9 @@
 
 #include "dptm_kernels.h"
 #include "dptm_layout.h"
+#include "dptm_phase.h"
 
 namespace dptm {
-
-#ifdef DPTM_PHASE_TIMING
-// Debug build only: cycles per phase summed over all wavefronts (phase ids in PH_MARK calls), read back with
-// dptm_debug_phase_cycles().  s_memtime is a read of the clock; the sums go out through vector atomics.
-__device__ unsigned long long g_phase_cycles[16];
-#define PH_DECL unsigned long long ph_t0 = __builtin_amdgcn_s_memtime(); unsigned long long ph_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define PH_MARK(id) { const unsigned long long ph_t1 = __builtin_amdgcn_s_memtime(); ph_acc[id] += ph_t1 - ph_t0; ph_t0 = ph_t1; }
-#define PH_FLUSH if ((threadIdx.x & 63) == 0) { for (int ph_i = 0; ph_i < 12; ++ph_i) atomicAdd(&g_phase_cycles[ph_i], ph_acc[ph_i]); }
-#else
-#define PH_DECL
-#define PH_MARK(id)
-#define PH_FLUSH
-#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -802,15 +790,6 @@ hipError_t launch_branch_h(int mode, int w, const float* params, const void* whi
     }
 }
 
-#ifdef DPTM_PHASE_TIMING
-extern "C" int dptm_debug_phase_cycles(unsigned long long* out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[16] = {};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_cycles), z, sizeof z) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
-
 }  // namespace dptm
+
+PH_DEFINE_READER(dptm_debug_phase_cycles_half)

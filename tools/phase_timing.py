@@ -1,21 +1,22 @@
-"""Per-phase cycles of the half-precision branch kernels (debug build with -DDPTM_PHASE_TIMING, selected
+"""Per-phase cycles of the branch kernels (debug build with -DDPTM_PHASE_TIMING, selected
 through DPTM_LIBRARY).  usage: DPTM_LIBRARY=$PWD/deepptmpred_amd/libdptm_phase.so python tools/phase_timing.py"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from deepptmpred_amd import spec, _native
 from deepptmpred_amd.model import Model
-names = ["conv2 (+barrier)", "x frags", "barrier A", "K,V,Q proj", "barrier B", "attention", "O proj+LN1", "FFN+LN2", "pooling", "setup+embedding", "barrier 0", "conv1"]
+names = ["conv2 (+barrier) [f32: whole conv block]", "x frags", "barrier A", "K,V,Q proj", "barrier B", "attention", "O proj+LN1", "FFN+LN2", "pooling", "setup+embedding", "barrier 0", "conv1"]
 m = Model(spec.synthetic_weights(7))
 lib = _native.load_library()
 x = spec.synthetic_inputs(32768, 3)
 buf = (C.c_ulonglong * 16)()
-for mode in ("bf16", "f16x3"):
+for mode in ("f32", "bf16", "f16x3"):
     m.scorer.set_precision(mode)
     m.predict(x)
-    lib.dptm_debug_phase_cycles(buf, 1)
+    rd = lib.dptm_debug_phase_cycles_f32 if mode == "f32" else lib.dptm_debug_phase_cycles_half
+    rd(buf, 1)
     m.predict(x)
-    lib.dptm_debug_phase_cycles(buf, 1)
+    rd(buf, 1)
     v = np.array(list(buf)[:12], dtype=np.float64)
     print(mode, "share of wavefront time per phase, all three branches (s_memtime ticks):")
     for n, c in zip(names, v):
