@@ -80,7 +80,19 @@ def keras_layer_table(spec: ModelSpec = DEFAULT_SPEC) -> List[Tuple[str, List[Tu
 
 
 def read_keras_h5(path: str, spec: ModelSpec = DEFAULT_SPEC) -> Dict[str, np.ndarray]:
-    """Canonical weight dict from a Keras-2 ``.h5`` model or weights file."""
+    """Canonical weight dict from a Keras-2 ``.h5`` model or weights file.  A damaged or truncated file
+    raises ``H5FormatError`` (a ``ValueError``), whatever low-level error the parser ran into."""
+    import struct
+    try:
+        return _read_keras_h5(path, spec)
+    except H5FormatError:
+        raise
+    except (struct.error, IndexError, KeyError, UnicodeDecodeError, OverflowError, RecursionError, MemoryError,
+            ValueError, TypeError, AttributeError, AssertionError) as e:
+        raise H5FormatError(f"{path}: not a readable Keras-2 HDF5 checkpoint ({type(e).__name__}: {e})") from e
+
+
+def _read_keras_h5(path: str, spec: ModelSpec) -> Dict[str, np.ndarray]:
     f = H5File(path)
     root = f["model_weights"] if "model_weights" in f.keys() and "layer_names" not in f.attrs else f
     shapes = dict(tensor_table(spec))

@@ -138,3 +138,37 @@ def test_wrong_layout_is_reported(tmp_path):
     w.save(p)
     with pytest.raises(H5FormatError):
         read_keras_h5(p)
+
+
+def test_damaged_files_raise_format_error(tmp_path):
+    """Truncation, flipped bytes and zeroed blocks end in H5FormatError (or, where the damage missed
+    everything the reader touches, in a clean read) -- never in a raw parser exception or a hang."""
+    from deepptmpred_amd import keras_h5
+    from deepptmpred_amd.hdf5_min import H5FormatError
+    w = spec.synthetic_weights(3)
+    good = tmp_path / "m.h5"
+    keras_h5.write_keras_h5(str(good), w)
+    raw = good.read_bytes()
+    rng = np.random.default_rng(0)
+    bad = tmp_path / "c.h5"
+    seen_error = 0
+    for trial in range(45):
+        b = bytearray(raw)
+        if trial % 3 == 0:
+            b = b[:int(rng.integers(16, len(b)))]
+        elif trial % 3 == 1:
+            for _ in range(8):
+                b[int(rng.integers(0, 20000))] = int(rng.integers(0, 256))
+        else:
+            i = int(rng.integers(0, len(b) - 64))
+            b[i:i + 64] = bytes(64)
+        bad.write_bytes(bytes(b))
+        try:
+            got = keras_h5.read_keras_h5(str(bad))
+            assert set(got) == set(w)
+        except H5FormatError:
+            seen_error += 1
+    assert seen_error >= 10
+    with pytest.raises(H5FormatError):
+        bad.write_bytes(b"not an hdf5 file at all")
+        keras_h5.read_keras_h5(str(bad))
