@@ -309,7 +309,7 @@ int make_dense(Reader& rd, int K, int N, int n_pad, bool bn, DenseLayer& L) {
 
 // half-precision images of a dense layer's kernel (layers with k % 16 == 0 and n % 128 == 0 only)
 int make_dense_half(const float* Wm, int K, int N, DenseLayer& L) {
-    if (K % 16 != 0 || N % 128 != 0) return DPTM_OK;
+    if (K % 32 != 0 || N % 128 != 0) return DPTM_OK;
     std::vector<uint16_t> hw((size_t)K * N);
     for (int kind = 0; kind < 3; ++kind) {
         pack_matrix_half(Wm, K, N, kind, hw.data());

@@ -623,8 +623,11 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
 // of a workgroup share the weight stream of one column slab); X stays fp32 in memory and is rounded (or
 // split) to operand fragments on the way in, so the layers around it keep their fp32 buffers.
 // ------------------------------------------------------------------------------------
+// Variant that fetches the operand order straight from memory (one lane per row).  Kept for the split mode,
+// where the staged variant below measures slower (its two-part fragments make the LDS round trip and the
+// conversions the bottleneck, not the fetch).
 template <int NT, int EPI, int MODE>
-__global__ __launch_bounds__(256, 2) void dense_kernel_h(DenseArgs p, const uint4* __restrict__ whi, const uint4* __restrict__ wlo) {
+__global__ __launch_bounds__(256, 2) void dense_kernel_h_direct(DenseArgs p, const uint4* __restrict__ whi, const uint4* __restrict__ wlo) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, j = lane & 31;
     const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
@@ -719,23 +722,146 @@ __global__ __launch_bounds__(256, 2) void dense_kernel_h(DenseArgs p, const uint
     }
 }
 
+constexpr int kStageStride = 36;   // floats per staged row: 32 + 4 keeps the fragment reads spread over the banks
+
+template <int NT, int EPI, int MODE>
+__global__ __launch_bounds__(256, 2) void dense_kernel_h(DenseArgs p, const uint4* __restrict__ whi, const uint4* __restrict__ wlo) {
+    // X is staged through LDS in blocks of 32 inputs: a wavefront fetches its 64 rows with every load
+    // instruction covering whole 128-byte lines (8 lanes per row), where a lane-per-row fetch of the MFMA
+    // operand order would touch 32 lines per instruction and use a quarter of each.  The staging area is
+    // private to the wavefront, so no workgroup barrier is needed (LDS operations of a wavefront stay ordered).
+    __shared__ __attribute__((aligned(16))) float stage_all[4][64 * kStageStride];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    if (r0 >= p.m) return;
+    float* stage = stage_all[wave];
+    const int slab = blockIdx.y;
+    const int KS = p.k >> 4, KB = p.k >> 5;
+    const size_t wbase = (size_t)slab * NT * KS * 64 + lane;
+
+    // fetch pattern: load i covers rows 8i .. 8i+7 of the tile, lane l -> row 8i + (l >> 3), floats 4*(l & 7)
+    const float* xsrc[8];
+    bool ok[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int64_t r = r0 + 8 * i + (lane >> 3);
+        if (r > p.m - 1) r = p.m - 1;
+        int64_t src = r;
+        ok[i] = true;
+        if (p.row_index) {
+            const int32_t s = p.row_index[r];
+            ok[i] = s >= 0;
+            src = s >= 0 ? s : 0;
+        }
+        xsrc[i] = p.x + src * p.ldx + 4 * (lane & 7);
+    }
+    float* st_w = stage + (lane >> 3) * kStageStride + 4 * (lane & 7);
+    const float* st_r[2] = {stage + j * kStageStride + 4 * h, stage + (32 + j) * kStageStride + 4 * h};
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = p.bias[h * (p.n_pad >> 3) + slab * NT * 4 + 4 * t + g];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][t][4 * g + e] = b[e];
+                acc[1][t][4 * g + e] = b[e];
+            }
+        }
+
+    // weight fragments one step ahead, except in the split mode whose fragments are twice as large
+    constexpr bool kAhead = !HP<MODE>::kSplit;
+    Frag<MODE> a_n[NT];
+    f32x4 xg[8];
+    if (kAhead) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a_n[t] = load_w<MODE>(whi + wbase, wlo + wbase, t * KS * 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xg[i] = *reinterpret_cast<const f32x4*>(xsrc[i]);
+    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(st_w + 8 * i * kStageStride) = ok[i] ? xg[i] : z;
+        }
+        if (kb + 1 < KB) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xg[i] = *reinterpret_cast<const f32x4*>(xsrc[i] + 32 * (kb + 1));
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ks = 2 * kb + kk;
+            Frag<MODE> a[NT], b[2];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a[t] = kAhead ? a_n[t] : load_w<MODE>(whi + wbase, wlo + wbase, (t * KS + ks) * 64);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                b[i] = make_frag<MODE>(*reinterpret_cast<const f32x4*>(st_r[i] + 16 * kk),
+                                       *reinterpret_cast<const f32x4*>(st_r[i] + 16 * kk + 8));
+            if (kAhead && ks + 1 < KS) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) a_n[t] = load_w<MODE>(whi + wbase, wlo + wbase, (t * KS + ks + 1) * 64);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                mac<MODE>(acc[0][t], a[t], b[0]);
+                mac<MODE>(acc[1][t], a[t], b[1]);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t r = r0 + 32 * i + j;
+        if (r >= p.m) continue;
+        float* orow = p.out + r * p.ldo + p.col_off + slab * NT * 32 + 4 * h;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[i][t][4 * g], acc[i][t][4 * g + 1], acc[i][t][4 * g + 2], acc[i][t][4 * g + 3]};
+                const int vi = h * (p.n_pad >> 3) + slab * NT * 4 + 4 * t + g;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = swish_h(v[e]);
+                if (EPI == kEpiSwishAffine) {
+                    const f32x4 sc = p.scale[vi], sh = p.shift[vi];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+                }
+                *reinterpret_cast<f32x4*>(orow + 32 * t + 8 * g) = v;
+            }
+    }
+}
+
 template <int MODE>
 static hipError_t launch_dense_h_m(const DenseArgs& a, int epi, const void* whi, const void* wlo, hipStream_t st) {
     const unsigned gx = (unsigned)((a.m + 255) / 256), gy = (unsigned)(a.n_pad / 128);
     const uint4* hi = reinterpret_cast<const uint4*>(whi);
     const uint4* lo = reinterpret_cast<const uint4*>(wlo);
-    if (epi == kEpiSwish)
-        hipLaunchKernelGGL((dense_kernel_h<4, kEpiSwish, MODE>), dim3(gx, gy), dim3(256), 0, st, a, hi, lo);
-    else if (epi == kEpiSwishAffine)
-        hipLaunchKernelGGL((dense_kernel_h<4, kEpiSwishAffine, MODE>), dim3(gx, gy), dim3(256), 0, st, a, hi, lo);
-    else
+    constexpr bool kDirect = HP<MODE>::kSplit;
+    if (epi == kEpiSwish) {
+        if (kDirect)
+            hipLaunchKernelGGL((dense_kernel_h_direct<4, kEpiSwish, MODE>), dim3(gx, gy), dim3(256), 0, st, a, hi, lo);
+        else
+            hipLaunchKernelGGL((dense_kernel_h<4, kEpiSwish, MODE>), dim3(gx, gy), dim3(256), 0, st, a, hi, lo);
+    } else if (epi == kEpiSwishAffine) {
+        if (kDirect)
+            hipLaunchKernelGGL((dense_kernel_h_direct<4, kEpiSwishAffine, MODE>), dim3(gx, gy), dim3(256), 0, st, a, hi, lo);
+        else
+            hipLaunchKernelGGL((dense_kernel_h<4, kEpiSwishAffine, MODE>), dim3(gx, gy), dim3(256), 0, st, a, hi, lo);
+    } else {
         return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_dense_h(int mode, const DenseArgs& a, int epi, const void* whi, const void* wlo, hipStream_t st) {
     if (a.m == 0) return hipSuccess;
-    if (a.n_pad % 128 != 0 || a.k % 16 != 0) return hipErrorInvalidValue;
+    if (a.n_pad % 128 != 0 || a.k % 32 != 0) return hipErrorInvalidValue;
     switch (mode) {
         case kModeBF16: return launch_dense_h_m<kModeBF16>(a, epi, whi, wlo, st);
         case kModeF16: return launch_dense_h_m<kModeF16>(a, epi, whi, wlo, st);
