@@ -271,7 +271,7 @@ def main() -> None:
     # the other arithmetic modes on the same resident inputs (rank 0, two steps each): reported
     # beside the headline, never as `value`
     variants = {}
-    if rank == 0 and not args.no_variants:
+    if rank == 0 and world == 1 and not args.no_variants:
         for mode in ("f32", "f16x3", "f16", "bf16"):
             if mode == args.precision:
                 continue
@@ -325,7 +325,7 @@ def main() -> None:
         }
         if variants:
             line["variants"] = variants
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only
             line["cpu_baseline"] = cpu_baseline(weights)
         print(json.dumps(line))
     if dist is not None:
