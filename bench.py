@@ -214,13 +214,22 @@ def main() -> None:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     dist = None
+    # rehearsal of the multi-rank path on a one-GPU box: DPTM_BENCH_REHEARSAL=1 puts every rank on GPU 0 and
+    # uses gloo for the barrier and the max-over-ranks reduction (RCCL refuses two ranks on one device)
+    rehearsal = os.environ.get("DPTM_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device(f"cuda:{local}"))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device(f"cuda:{local}"))
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
+    rdev = torch.device("cpu") if rehearsal else dev      # where the reduced scalar lives
 
     from deepptmpred_amd import spec
     from deepptmpred_amd.model import Model
@@ -254,7 +263,7 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=rdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -307,7 +316,8 @@ def main() -> None:
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic (device-generated sites, seeded synthetic weights)",
-            "config": {"workload": "config 3: 1M synthetic sites (windows 21/33/51 + ESM-2 1280 + 8 struct), fp32, 1 MI355X",
+            "config": {"workload": f"config 3: {n:,} synthetic sites per GPU (windows 21/33/51 + ESM-2 1280 + 8 struct), "
+                                   f"{args.precision}, {world} x MI355X",
                        "sites_per_gpu": n, "parallelism": f"dp{world} (sites sharded, no collective)"},
             "roofline": {"bound": "mfma", "kernel": KERNEL_NAME[args.precision], "achieved": achieved,
                          "peak": PEAK_MFMA[args.precision], "unit": "TFLOP/s",
