@@ -210,6 +210,8 @@ int64_t weight_count() {
     return total;
 }
 
+inline bool misaligned(const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) != 0; }
+
 int upload(const std::vector<float>& v, float** d) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(d), v.size() * sizeof(float)));
     HIP_TRY(hipMemcpy(*d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -673,6 +675,9 @@ int dptm_score_device(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33
     if (n == 0) return DPTM_OK;
     if (!tok21 || !tok33 || !tok51 || !strct || !esm || !out)
         return fail(DPTM_EINVAL, "dptm_score_device: NULL buffer");
+    // the kernels read rows with 16-byte vector loads and store probability pairs with 8-byte stores
+    if (misaligned(strct, 16) || misaligned(esm, 16) || misaligned(out, 8))
+        return fail(DPTM_EINVAL, "dptm_score_device: struct / esm must be 16-byte aligned, out 8-byte aligned");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
     for (int64_t c0 = 0; c0 < n; c0 += kChunkSites) {
@@ -708,6 +713,8 @@ int dptm_score_protein_device(dptm_handle* h, const uint8_t* codes, int64_t L, c
     if (n == 0) return DPTM_OK;
     if (!codes || !positions || !strct || !out || (esm_rows > 0 && !esm_table))
         return fail(DPTM_EINVAL, "dptm_score_protein_device: NULL buffer");
+    if (misaligned(strct, 16) || (esm_rows > 0 && misaligned(esm_table, 16)) || misaligned(out, 8) || misaligned(positions, 4))
+        return fail(DPTM_EINVAL, "dptm_score_protein_device: struct / esm table must be 16-byte aligned, out 8-byte, positions 4-byte");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
     const float* table = esm_rows > 0 ? esm_table : h->d_zero_row;

@@ -100,7 +100,10 @@ int dptm_score_protein(dptm_handle* h, const uint8_t* codes, int64_t L, const fl
  * is enqueued on `stream` (a hipStream_t passed as void*; NULL = the handle's own
  * stream) and the call returns without waiting.  These are what the batch scheduler
  * and bench.py drive; they have no counterpart in the reference, which only ever hands
- * host arrays to Keras. */
+ * host arrays to Keras.  The kernels fetch rows as 16-byte vectors and store the two
+ * probabilities as one pair: strct / esm / esm_table must be 16-byte aligned, out 8-byte,
+ * positions 4-byte (any hipMalloc or framework allocation is; a pointer offset into a
+ * row is not) — otherwise DPTM_EINVAL and nothing is enqueued. */
 int dptm_score_device(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33,
                       const uint8_t* tok51, const float* strct, const float* esm, int64_t n,
                       float* out, void* stream);

@@ -164,6 +164,27 @@ def test_device_entry_matches_host_entry(model):
     assert np.array_equal(out.cpu().numpy(), host)
 
 
+def test_device_entry_rejects_misaligned_buffers(model):
+    """The kernels fetch struct / ESM rows as 16-byte vectors and store the two probabilities
+    as one 8-byte pair: a pointer off those boundaries is refused before any launch."""
+    import torch
+    dev = torch.device("cuda:0")
+    x = spec.synthetic_inputs(64, 22)
+    d = [torch.from_numpy(a).to(dev) for a in x]
+    out = torch.empty((65, 2), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    args = [d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), 64,
+            out.data_ptr(), st]
+    for slot, off in ((3, 4), (4, 4), (6, 4)):
+        bad = list(args)
+        bad[slot] += off
+        with pytest.raises(ValueError, match="aligned"):
+            model.scorer.score_device(*bad)
+    model.scorer.score_device(*args)                          # the handle still works afterwards
+    torch.cuda.synchronize()
+    assert np.array_equal(out[:64].cpu().numpy(), model.predict(x))
+
+
 def test_bad_position_is_rejected(model):
     with pytest.raises(IndexError):
         model.predict_protein("ACDEFGHIK", [0], np.zeros((1, 8)))
