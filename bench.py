@@ -189,8 +189,99 @@ def train_main(args) -> None:
         dist.destroy_process_group()
 
 
+def sweep_main(args) -> None:
+    """--types T: the same resident sites scored by T weight sets (BASELINE config 4: every PTM type has
+    its own model, predict.py:119-137).  Sites are sharded over ranks, every rank holds all T models
+    (6.5 MB each), inputs are read T times from HBM and never re-uploaded.  `value` counts
+    (site, type) scorings per second; rank 0 also times the host-array form (one upload per pass
+    shared by all types) on a bounded sample."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    from deepptmpred_amd import spec
+    from deepptmpred_amd.model import Model
+    from deepptmpred_amd.sharding import predict_all_types
+
+    T = args.types
+    models = {f"type{k:02d}": Model(spec.synthetic_weights(100 + k), device=local) for k in range(T)}
+    for m in models.values():
+        m.scorer.set_precision(args.precision)
+    n = args.sites
+    x = device_inputs(n, 1234 + rank, dev)
+    outs = [torch.empty((n, 2), device=dev, dtype=torch.float32) for _ in range(T)]
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+    ptrs = [t.data_ptr() for t in x]
+
+    def step():
+        for m, o in zip(models.values(), outs):
+            m.scorer.score_device(ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], n, o.data_ptr(), stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    for o in outs:
+        chk = o[:: max(1, n // 1024)].cpu().numpy()
+        assert np.isfinite(chk).all() and np.abs(chk.sum(axis=1) - 1).max() < 1e-5
+    # different weight sets must give different answers (the models are really distinct)
+    assert float((outs[0][:1024] - outs[-1][:1024]).abs().max().item()) > 0 or T == 1
+
+    streamed = None
+    if rank == 0:
+        m = min(n, 262144)
+        hx = spec.synthetic_inputs(m, 77)
+        predict_all_types(models, [a[:4096] for a in hx])            # warm-up: pinned buffers, first launches
+        t1 = time.perf_counter()
+        res = predict_all_types(models, hx)
+        dt = time.perf_counter() - t1
+        assert len(res) == T
+        streamed = {"site_types_per_s_one_gpu": m * T / dt, "sites": m,
+                    "note": "host arrays in, host arrays out; one upload per pass shared by all types"}
+    barrier()
+    if rank == 0:
+        value = world * n * T * args.steps / elapsed
+        print(json.dumps({
+            "metric": "windows x PTM types scored/sec", "value": value, "unit": "site-types/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
+            "data": "synthetic (device-generated sites, seeded synthetic weight sets 100..)",
+            "config": {"workload": f"config 4: {n:,} resident sites per GPU x {T} weight sets, {args.precision}, "
+                                   f"{world} x MI355X", "sites_per_gpu": n, "types": T,
+                       "parallelism": f"dp{world} (sites sharded, every rank holds all {T} models, no collective)"},
+            "whole_path": {"tflops": value / world * FLOPS_PER_SITE / 1e12,
+                           "sites_per_s_all_types": value / T},
+            "streamed_from_host": streamed}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
+    ap.add_argument("--types", type=int, default=0,
+                    help="score the resident sites with this many weight sets (BASELINE config 4) instead")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
@@ -206,6 +297,8 @@ def main() -> None:
     args = ap.parse_args()
     if args.train:
         return train_main(args)
+    if args.types > 0:
+        return sweep_main(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

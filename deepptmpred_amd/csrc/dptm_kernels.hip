@@ -26,6 +26,8 @@ __device__ __forceinline__ void mfma(f32x16& acc, float a, float b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
 }
 
+constexpr float kQScale = 0.25f * 1.44269504088896340736f;  // log2(e) / sqrt(head_dim)
+
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // keras 'swish': x * sigmoid(x)
@@ -123,6 +125,118 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// value held by the neighbouring lane (lane ^ 1): a quad permutation [1,0,3,2] on the DPP path
+__device__ __forceinline__ float lane_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+
+// Softmax attention of NR query rows of one site against that site's W keys for one head
+// (model.py:62-71; q arrives scaled by log2(e)/sqrt(16), so exponentials are base 2).  kp / vp: first key / value row of
+// the site in LDS at this head's 16 features.  Keys are walked in three chunks of W/3 with a
+// running maximum (the usual rescaling form of softmax), which keeps only W/3 scores live per
+// row; every K / V fragment read serves all NR rows.
+template <int W, int NR>
+__device__ __forceinline__ void attend(const float* kp, const float* vp, const float (&q)[NR][16],
+                                       float (&o)[NR][16]) {
+    constexpr int CH = W / 3;
+    static_assert(CH * 3 == W, "window sizes are multiples of 3");
+    float m[NR], den[NR];
+    f32x4 acc[NR][4];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        m[r] = -3.0e38f;
+        den[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+        float sc[NR][CH];
+        float cm[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) cm[r] = -3.0e38f;
+        // K / V fragments are requested one key ahead of the products that consume them (two register
+        // sets); the sched_barrier keeps the compiler from sinking the request back to its use
+        f32x4 kb[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kb[0][i] = *reinterpret_cast<const f32x4*>(kp + 4 * i);
+#pragma unroll
+        for (int t = 0; t < CH; ++t) {
+            if (t + 1 < CH) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    kb[(t + 1) & 1][i] = *reinterpret_cast<const f32x4*>(kp + (t + 1) * kLdsStride + 4 * i);
+            }
+            const f32x4 (&k)[4] = kb[t & 1];
+            // two partial sums per row so that the 16 products go through 8 packed FMAs; the rows'
+            // chains are written interleaved so that consecutive instructions are independent
+            f32x2 a2[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) a2[r] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; e += 2)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+                        a2[r] += f32x2{q[r][4 * i + e], q[r][4 * i + e + 1]} * f32x2{k[i][e], k[i][e + 1]};
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const float a = a2[r][0] + a2[r][1];
+                sc[r][t] = a;
+                cm[r] = fmaxf(cm[r], a);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 vb[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vb[0][i] = *reinterpret_cast<const f32x4*>(vp + 4 * i);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const float mn = fmaxf(m[r], cm[r]);
+            const float alpha = __builtin_amdgcn_exp2f(m[r] - mn);
+            m[r] = mn;
+            den[r] *= alpha;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[r][i] *= alpha;
+        }
+        // all exponentials of the chunk first (independent of each other, so the quarter-rate unit
+        // pipelines them), then the weighted sum
+#pragma unroll
+        for (int t = 0; t < CH; ++t)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                sc[r][t] = __builtin_amdgcn_exp2f(sc[r][t] - m[r]);
+                den[r] += sc[r][t];
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < CH; ++t) {
+            if (t + 1 < CH) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    vb[(t + 1) & 1][i] = *reinterpret_cast<const f32x4*>(vp + (t + 1) * kLdsStride + 4 * i);
+            }
+            const f32x4 (&v)[4] = vb[t & 1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) acc[r][i] += sc[r][t] * v[i];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        kp += CH * kLdsStride;
+        vp += CH * kLdsStride;
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const float rden = 1.0f / den[r];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[r][4 * i + e] = acc[r][i][e] * rden;
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // Fused sequence branch.  One workgroup = 8 wavefronts = one tile of S = 256/W whole
 // sites (S*W <= 256 rows, row = site_in_tile*W + position); wavefront w owns rows
@@ -177,7 +291,10 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
     const bool row_ok = row < rows_valid;
     const int site_l = row_ok ? row / W : 0;
     const int pos_l = row_ok ? row - site_l * W : 1;
-    const int row_start = site_l * W;  // first row of this lane's site (0 for padding rows)
+    // first key row of the site whose keys this row (and its pair row, row ^ 1) attends to; padding rows at the
+    // end of the tile borrow the last site so that they never split a pair
+    const int att_start = min(row / W, S - 1) * W;
+    const int att_start_pair = min((row ^ 1) / W, S - 1) * W;
     const bool tap0_ok = row_ok && pos_l > 0;
     const bool tap2_ok = row_ok && pos_l < W - 1;
 
@@ -315,8 +432,8 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
                     *reinterpret_cast<f32x4*>(vb + 8 * (4 * t + g)) =
                         f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
         }
-        // q, scaled by 1/sqrt(head_dim) = 1/4 (exact), regrouped so that the lower
-        // half-wave holds heads 0,1 and the upper half-wave heads 2,3 of its row
+        // q, scaled by log2(e)/sqrt(head_dim) (the softmax below works in base 2), regrouped so
+        // that the lower half-wave holds heads 0,1 and the upper half-wave heads 2,3 of its row
         float qa[16], qb[16];
         {
             f32x16 acc[2];
@@ -324,74 +441,55 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
             gemm_regs<8, 2>(acc, T + kTbWq, x1, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                qa[r] = acc[0][r] * 0.25f;
-                qb[r] = acc[1][r] * 0.25f;
+                qa[r] = acc[0][r] * kQScale;
+                qb[r] = acc[1][r] * kQScale;
                 half_swap(qa[r], qb[r]);
             }
         }
         PH_MARK(3)   // K, V, Q projections
         __syncthreads();  // K and V of the whole tile are in LDS
         PH_MARK(4)   // barrier wait
-        // attention: this lane = (query row, two heads).  After the regrouping,
-        // qa[4u+e] / qb[4u+e] hold features 32h + 8u + e / 32h + 8u + 4 + e.
-        // Keys are walked in three chunks of W/3 with a running maximum (the usual
-        // rescaling form of softmax), which keeps only W/3 scores live per lane.
+        // attention: lanes j and j^1 of a half-wave pair up.  Each takes ONE of the half-wave's two heads
+        // (head 2h + (j&1)) for BOTH rows of the pair, so every K / V fragment read from LDS serves two
+        // query rows.  The lanes trade the 16 query values of the head they give away (one DPP move each).
+        {
+            const bool odd = (j & 1) != 0;
+            float q[2][16], o[2][16];
 #pragma unroll
-        for (int hd = 0; hd < 2; ++hd) {
-            constexpr int CH = W / 3;
-            static_assert(CH * 3 == W, "window sizes are multiples of 3");
-            const float* kp = bufA + row_start * kLdsStride + 32 * h + 16 * hd;
-            const float* vp = bufB + row_start * kLdsStride + 32 * h + 16 * hd;
-            float m = -3.0e38f, den = 0.f;
-            f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0, o2 = o0, o3 = o0;
-#pragma unroll 1
-            for (int c = 0; c < 3; ++c) {
-                float sc[CH];
-                float cm = -3.0e38f;
-#pragma unroll
-                for (int t = 0; t < CH; ++t) {
-                    const f32x4 k0 = *reinterpret_cast<const f32x4*>(kp + t * kLdsStride);
-                    const f32x4 k1 = *reinterpret_cast<const f32x4*>(kp + t * kLdsStride + 4);
-                    const f32x4 k2 = *reinterpret_cast<const f32x4*>(kp + t * kLdsStride + 8);
-                    const f32x4 k3 = *reinterpret_cast<const f32x4*>(kp + t * kLdsStride + 12);
-                    // two partial sums so that the 16 products go through 8 packed FMAs
-                    f32x2 a2 = {0.f, 0.f};
-#pragma unroll
-                    for (int e = 0; e < 4; e += 2) {
-                        a2 += f32x2{qa[8 * hd + e], qa[8 * hd + e + 1]} * f32x2{k0[e], k0[e + 1]};
-                        a2 += f32x2{qb[8 * hd + e], qb[8 * hd + e + 1]} * f32x2{k1[e], k1[e + 1]};
-                        a2 += f32x2{qa[8 * hd + 4 + e], qa[8 * hd + 5 + e]} * f32x2{k2[e], k2[e + 1]};
-                        a2 += f32x2{qb[8 * hd + 4 + e], qb[8 * hd + 5 + e]} * f32x2{k3[e], k3[e + 1]};
-                    }
-                    const float a = a2[0] + a2[1];
-                    sc[t] = a;
-                    cm = fmaxf(cm, a);
-                }
-                const float mn = fmaxf(m, cm);
-                const float alpha = __expf(m - mn);
-                m = mn;
-                den *= alpha;
-                o0 *= alpha; o1 *= alpha; o2 *= alpha; o3 *= alpha;
-#pragma unroll
-                for (int t = 0; t < CH; ++t) {
-                    const float pr = __expf(sc[t] - mn);
-                    den += pr;
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(vp + t * kLdsStride);
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(vp + t * kLdsStride + 4);
-                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(vp + t * kLdsStride + 8);
-                    const f32x4 v3 = *reinterpret_cast<const f32x4*>(vp + t * kLdsStride + 12);
-                    o0 += pr * v0; o1 += pr * v1; o2 += pr * v2; o3 += pr * v3;
-                }
-                kp += CH * kLdsStride;
-                vp += CH * kLdsStride;
+            for (int d = 0; d < 16; ++d) {
+                // d-th feature of local head 0 / 1 of this lane's row
+                const int src = 4 * (d >> 3) + (d & 3);
+                const float h0 = (d & 4) ? qb[src] : qa[src];
+                const float h1 = (d & 4) ? qb[8 + src] : qa[8 + src];
+                q[0][d] = odd ? h1 : h0;
+                q[1][d] = lane_xor1(odd ? h0 : h1);
             }
-            const float rden = 1.0f / den;
+            const int head_off = 32 * h + (odd ? 16 : 0);
+            const float* kp0 = bufA + att_start * kLdsStride + head_off;
+            const float* kp1 = bufA + att_start_pair * kLdsStride + head_off;
+            const int v_off = kTileRows * kLdsStride;       // bufB = bufA + v_off
+            if (__builtin_amdgcn_ballot_w64(att_start != att_start_pair) == 0) {
+                attend<W, 2>(kp0, kp0 + v_off, q, o);
+            } else {
+                // a pair in this wavefront straddles two sites: the rows walk their own keys
+                float q1[1][16], o1[1][16];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                qa[8 * hd + e] = o0[e] * rden;
-                qb[8 * hd + e] = o1[e] * rden;
-                qa[8 * hd + 4 + e] = o2[e] * rden;
-                qb[8 * hd + 4 + e] = o3[e] * rden;
+                for (int d = 0; d < 16; ++d) q1[0][d] = q[0][d];
+                attend<W, 1>(kp0, kp0 + v_off, q1, o1);
+#pragma unroll
+                for (int d = 0; d < 16; ++d) { o[0][d] = o1[0][d]; q1[0][d] = q[1][d]; }
+                attend<W, 1>(kp1, kp1 + v_off, q1, o1);
+#pragma unroll
+                for (int d = 0; d < 16; ++d) o[1][d] = o1[0][d];
+            }
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {
+                const float got = lane_xor1(o[1][d]);       // this lane's row, the other head
+                const int dst = 4 * (d >> 3) + (d & 3);
+                const float h0 = odd ? got : o[0][d];
+                const float h1 = odd ? o[0][d] : got;
+                if (d & 4) { qb[dst] = h0; qb[8 + dst] = h1; }
+                else       { qa[dst] = h0; qa[8 + dst] = h1; }
             }
         }
         PH_MARK(5)   // attention

@@ -9,7 +9,7 @@ names = ["conv2 (+barrier) [f32: whole conv block]", "x frags", "barrier A", "K,
 m = Model(spec.synthetic_weights(7))
 lib = _native.load_library()
 x = spec.synthetic_inputs(32768, 3)
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 32)()
 for mode in ("f32", "bf16", "f16x3"):
     m.scorer.set_precision(mode)
     m.predict(x)
@@ -21,6 +21,8 @@ for mode in ("f32", "bf16", "f16x3"):
     print(mode, "share of wavefront time per phase, all three branches (s_memtime ticks):")
     for n, c in zip(names, v):
         print("   %-14s %5.1f %%" % (n, 100 * c / v.sum()))
+    w = np.array(list(buf)[16:32], dtype=np.float64)
+    print("   per wavefront index, %% of all time: barrier waits", np.round(100 * w[:8] / v.sum(), 2), "attention", np.round(100 * w[8:] / v.sum(), 2))
     tiles = -(-32768 // 12) + -(-32768 // 7) + -(-32768 // 5)
     print("   ticks per wavefront-tile: %.0f  (tiles %d; compare with the kernels' tile period)" % (v.sum() / (tiles * 8), tiles))
     m.scorer.profile_begin(); m.predict(x); pr = m.scorer.profile_end()
