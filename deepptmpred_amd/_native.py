@@ -181,6 +181,16 @@ def _ptr(a: np.ndarray) -> C.c_void_p:
     return C.c_void_p(a.ctypes.data)
 
 
+def _buffer(a, dtype, shape, what: str) -> np.ndarray:
+    """The C side reads raw memory: refuse anything but a C-contiguous array of exactly this dtype and
+    shape (``None`` = any length in that axis) instead of letting it read past the end."""
+    if not isinstance(a, np.ndarray) or a.dtype != np.dtype(dtype) or not a.flags.c_contiguous:
+        raise ValueError(f"{what}: expected a C-contiguous numpy array of dtype {np.dtype(dtype).name}")
+    if a.ndim != len(shape) or any(w is not None and a.shape[i] != w for i, w in enumerate(shape)):
+        raise ValueError(f"{what}: expected shape {tuple('n' if w is None else w for w in shape)}, got {a.shape}")
+    return a
+
+
 def sasa(xyz: np.ndarray, radii: np.ndarray, probe: float, unit_points: np.ndarray, device: int = 0) -> np.ndarray:
     """Per-atom solvent-accessible area on the GPU (``dptm_sasa``); float64 in, float64 out."""
     lib = load_library()
@@ -228,6 +238,11 @@ class Scorer:
     # ---- host-buffer calls (numpy in, numpy out)
     def score(self, tok21, tok33, tok51, strct, esm) -> np.ndarray:
         n = len(tok21)
+        ws = self.spec.window_sizes
+        for a, w, name in ((tok21, ws[0], "tok21"), (tok33, ws[1], "tok33"), (tok51, ws[2], "tok51")):
+            _buffer(a, np.uint8, (n, w), f"dptm_score: {name}")
+        _buffer(strct, np.float32, (n, self.spec.struct_feature_dim), "dptm_score: struct")
+        _buffer(esm, np.float32, (n, self.spec.esm_dim), "dptm_score: esm")
         out = np.empty((n, 2), dtype=np.float32)
         rc = self._lib.dptm_score(self._h, _ptr(tok21), _ptr(tok33), _ptr(tok51), _ptr(strct),
                                   _ptr(esm), n, _ptr(out))
@@ -236,6 +251,11 @@ class Scorer:
 
     def score_protein(self, codes, esm_table, positions, strct) -> np.ndarray:
         n = len(positions)
+        _buffer(codes, np.uint8, (None,), "dptm_score_protein: codes")
+        _buffer(positions, np.int32, (n,), "dptm_score_protein: positions")
+        _buffer(strct, np.float32, (n, self.spec.struct_feature_dim), "dptm_score_protein: struct")
+        if esm_table is not None and len(esm_table):
+            _buffer(esm_table, np.float32, (None, self.spec.esm_dim), "dptm_score_protein: esm table")
         out = np.empty((n, 2), dtype=np.float32)
         rows = 0 if esm_table is None else len(esm_table)
         tp = C.c_void_p(None) if esm_table is None or rows == 0 else _ptr(esm_table)

@@ -6,6 +6,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -22,6 +24,26 @@ thread_local std::string g_err;
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
+    return code;
+}
+
+// A C++ exception must not leave an extern "C" function: every entry point is a function-try-block
+// whose handler lands here, turns the exception into a return code and records the message.
+int on_exception(const char* where) noexcept {
+    int code = DPTM_EHIP;
+    try {
+        try {
+            throw;
+        } catch (const std::bad_alloc&) {
+            code = DPTM_ENOMEM;
+            g_err = std::string(where) + ": out of host memory";
+        } catch (const std::exception& e) {
+            g_err = std::string(where) + ": " + e.what();
+        } catch (...) {
+            g_err = std::string(where) + ": unknown C++ exception";
+        }
+    } catch (...) {   // even the message could not be stored
+    }
     return code;
 }
 
@@ -457,11 +479,17 @@ void parallel_copy(void* dst, const void* src, size_t bytes) {
     }
     const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
     std::vector<std::thread> pool;
+    pool.reserve(nt);
     for (size_t t = 1; t < nt; ++t) {
         const size_t off = t * per;
         if (off >= bytes) break;
         const size_t len = std::min(per, bytes - off);
-        pool.emplace_back([=] { std::memcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, len); });
+        try {
+            pool.emplace_back([=] { std::memcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, len); });
+        } catch (...) {   // no more threads to be had: this slice and the rest are copied here
+            std::memcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, bytes - off);
+            break;
+        }
     }
     std::memcpy(dst, src, std::min(per, bytes));
     for (auto& th : pool) th.join();
@@ -515,6 +543,19 @@ int build_half_images(dptm_handle* h) {
     h->half_ready = true;
     return DPTM_OK;
 }
+
+// The host-buffer entry points enqueue copies out of the caller's arrays.  On any early return the
+// work already queued is waited for, so that nothing reads those arrays (or the staging slots a later
+// call will refill) after the call has reported its error.
+struct DrainOnError {
+    dptm_handle* h;
+    bool armed = true;
+    ~DrainOnError() {
+        if (!armed) return;
+        if (h->stream) (void)hipStreamSynchronize(h->stream);
+        if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+    }
+};
 
 }  // namespace
 
@@ -575,7 +616,7 @@ void dptm_destroy(dptm_handle* h) {
     delete h;
 }
 
-int dptm_create(const void* weights, size_t nbytes, const dptm_spec* spec, int device, dptm_handle** out) {
+int dptm_create(const void* weights, size_t nbytes, const dptm_spec* spec, int device, dptm_handle** out) try {
     if (!out) return fail(DPTM_EINVAL, "dptm_create: out is NULL");
     *out = nullptr;
     if (!weights) return fail(DPTM_EINVAL, "dptm_create: weights is NULL");
@@ -601,14 +642,10 @@ int dptm_create(const void* weights, size_t nbytes, const dptm_spec* spec, int d
 
     dptm_handle* h = new (std::nothrow) dptm_handle();
     if (!h) return fail(DPTM_ENOMEM, "dptm_create: out of host memory");
+    std::unique_ptr<dptm_handle, void (*)(dptm_handle*)> owner(h, dptm_destroy);   // released on success only
     h->device = device;
     int rc = DPTM_OK;
-    auto bail = [&](int code) {
-        std::string keep = g_err;
-        dptm_destroy(h);
-        g_err = keep;
-        return code;
-    };
+    auto bail = [&](int code) { return code; };   // `owner` frees the half-built handle on every early return
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(DPTM_EHIP, "dptm_create: hipStreamCreate failed"));
 
@@ -643,13 +680,15 @@ int dptm_create(const void* weights, size_t nbytes, const dptm_spec* spec, int d
         if ((rc = dalloc((void**)&h->d_tok[b], kChunkSites * (size_t)kWin[b]))) return bail(rc);
     if ((rc = dalloc((void**)&h->d_esm_row, kChunkSites * sizeof(int32_t)))) return bail(rc);
     if (hipDeviceSynchronize() != hipSuccess) return bail(fail(DPTM_EHIP, "dptm_create: device sync failed"));
-    *out = h;
+    *out = owner.release();
     return DPTM_OK;
+} catch (...) {
+    return on_exception("dptm_create");
 }
 
 int64_t dptm_chunk_sites(const dptm_handle* h) { return h ? kChunkSites : 0; }
 
-int dptm_set_precision(dptm_handle* h, int mode) {
+int dptm_set_precision(dptm_handle* h, int mode) try {
     if (!h) return fail(DPTM_EINVAL, "dptm_set_precision: NULL handle");
     if (mode != kModeF32 && mode != kModeBF16 && mode != kModeF16 && mode != kModeF16X3)
         return fail(DPTM_EINVAL, "dptm_set_precision: unknown mode");
@@ -659,17 +698,21 @@ int dptm_set_precision(dptm_handle* h, int mode) {
     }
     h->precision = mode;
     return DPTM_OK;
+} catch (...) {
+    return on_exception("dptm_set_precision");
 }
 
-int dptm_sync(dptm_handle* h) {
+int dptm_sync(dptm_handle* h) try {
     if (!h) return fail(DPTM_EINVAL, "dptm_sync: NULL handle");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return DPTM_OK;
+} catch (...) {
+    return on_exception("dptm_sync");
 }
 
 int dptm_score_device(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
-                      const float* strct, const float* esm, int64_t n, float* out, void* stream) {
+                      const float* strct, const float* esm, int64_t n, float* out, void* stream) try {
     if (!h) return fail(DPTM_EINVAL, "dptm_score_device: NULL handle");
     if (n < 0) return fail(DPTM_EINVAL, "dptm_score_device: n < 0");
     if (n == 0) return DPTM_OK;
@@ -688,11 +731,13 @@ int dptm_score_device(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33
         if (rc) return rc;
     }
     return DPTM_OK;
+} catch (...) {
+    return on_exception("dptm_score_device");
 }
 
 int dptm_assemble_device(dptm_handle* h, const uint8_t* codes, int64_t L, int64_t esm_rows,
                          const int32_t* positions, int64_t n, uint8_t* tok21, uint8_t* tok33,
-                         uint8_t* tok51, int32_t* esm_row, void* stream) {
+                         uint8_t* tok51, int32_t* esm_row, void* stream) try {
     if (!h) return fail(DPTM_EINVAL, "dptm_assemble_device: NULL handle");
     if (n < 0 || L < 0 || esm_rows < 0) return fail(DPTM_EINVAL, "dptm_assemble_device: negative size");
     if (n == 0) return DPTM_OK;
@@ -703,11 +748,13 @@ int dptm_assemble_device(dptm_handle* h, const uint8_t* codes, int64_t L, int64_
     Prof p(h, st, DPTM_PROF_ASSEMBLE);
     HIP_TRY(launch_assemble(codes, L, esm_rows, positions, n, tok21, tok33, tok51, esm_row, st));
     return DPTM_OK;
+} catch (...) {
+    return on_exception("dptm_assemble_device");
 }
 
 int dptm_score_protein_device(dptm_handle* h, const uint8_t* codes, int64_t L, const float* esm_table,
                               int64_t esm_rows, const int32_t* positions, const float* strct, int64_t n,
-                              float* out, void* stream) {
+                              float* out, void* stream) try {
     if (!h) return fail(DPTM_EINVAL, "dptm_score_protein_device: NULL handle");
     if (n < 0 || L < 0 || esm_rows < 0) return fail(DPTM_EINVAL, "dptm_score_protein_device: negative size");
     if (n == 0) return DPTM_OK;
@@ -728,10 +775,12 @@ int dptm_score_protein_device(dptm_handle* h, const uint8_t* codes, int64_t L, c
         if (rc) return rc;
     }
     return DPTM_OK;
+} catch (...) {
+    return on_exception("dptm_score_protein_device");
 }
 
 int dptm_score(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
-               const float* strct, const float* esm, int64_t n, float* out) {
+               const float* strct, const float* esm, int64_t n, float* out) try {
     if (!h) return fail(DPTM_EINVAL, "dptm_score: NULL handle");
     if (n < 0) return fail(DPTM_EINVAL, "dptm_score: n < 0");
     if (n == 0) return DPTM_OK;
@@ -739,6 +788,7 @@ int dptm_score(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const
     HIP_TRY(hipSetDevice(h->device));
     int rc = ensure_host_staging(h);
     if (rc) return rc;
+    DrainOnError drain{h};
     if (n <= kChunkSites) {
         // one pass: nothing to overlap, and the pinned staging blocks of the pipeline (2 x 172 MB) are not
         // worth allocating for a protein's worth of sites
@@ -750,6 +800,7 @@ int dptm_score(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const
         if ((rc = score_chunk(h, tok, h->s_strct, h->s_esm, kEsm, nullptr, n, h->s_out, h->stream))) return rc;
         HIP_TRY(hipMemcpyAsync(out, h->s_out, n * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+        drain.armed = false;
         return DPTM_OK;
     }
     if ((rc = ensure_pipeline(h))) return rc;
@@ -794,12 +845,15 @@ int dptm_score(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const
         prev_m = m;
     }
     if ((rc = retire((int)((i - 1) & 1), prev_c0, prev_m))) return rc;
+    drain.armed = false;
     return DPTM_OK;
+} catch (...) {
+    return on_exception("dptm_score");
 }
 
 int dptm_score_protein(dptm_handle* h, const uint8_t* codes, int64_t L, const float* esm_table,
                        int64_t esm_rows, const int32_t* positions, const float* strct, int64_t n,
-                       float* out) {
+                       float* out) try {
     if (!h) return fail(DPTM_EINVAL, "dptm_score_protein: NULL handle");
     if (n < 0 || L < 0 || esm_rows < 0) return fail(DPTM_EINVAL, "dptm_score_protein: negative size");
     if (n == 0) return DPTM_OK;
@@ -829,6 +883,7 @@ int dptm_score_protein(dptm_handle* h, const uint8_t* codes, int64_t L, const fl
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->s_table), (size_t)esm_rows * kEsm * sizeof(float)));
         h->s_table_cap = esm_rows;
     }
+    DrainOnError drain{h};
     HIP_TRY(hipMemcpyAsync(h->s_codes, codes, (size_t)L, hipMemcpyHostToDevice, h->stream));
     if (esm_rows > 0)
         HIP_TRY(hipMemcpyAsync(h->s_table, esm_table, (size_t)esm_rows * kEsm * sizeof(float), hipMemcpyHostToDevice, h->stream));
@@ -842,10 +897,13 @@ int dptm_score_protein(dptm_handle* h, const uint8_t* codes, int64_t L, const fl
         HIP_TRY(hipMemcpyAsync(out + c0 * 2, h->s_out, m * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
+    drain.armed = false;
     return DPTM_OK;
+} catch (...) {
+    return on_exception("dptm_score_protein");
 }
 
-int dptm_profile_begin(dptm_handle* h) {
+int dptm_profile_begin(dptm_handle* h) try {
     if (!h) return fail(DPTM_EINVAL, "dptm_profile_begin: NULL handle");
     for (auto& r : h->prof) {
         (void)hipEventDestroy(r.a);
@@ -854,9 +912,11 @@ int dptm_profile_begin(dptm_handle* h) {
     h->prof.clear();
     h->prof_armed = true;
     return DPTM_OK;
+} catch (...) {
+    return on_exception("dptm_profile_begin");
 }
 
-int dptm_profile_end(dptm_handle* h, float* ms, int64_t* launches) {
+int dptm_profile_end(dptm_handle* h, float* ms, int64_t* launches) try {
     if (!h || !ms || !launches) return fail(DPTM_EINVAL, "dptm_profile_end: NULL argument");
     h->prof_armed = false;
     HIP_TRY(hipSetDevice(h->device));
@@ -878,6 +938,8 @@ int dptm_profile_end(dptm_handle* h, float* ms, int64_t* launches) {
     }
     h->prof.clear();
     return rc;
+} catch (...) {
+    return on_exception("dptm_profile_end");
 }
 
 }  // extern "C"

@@ -11,6 +11,8 @@
 // L2), then one thread per test point walks the neighbour list with early exit.
 #include <hip/hip_runtime.h>
 
+#include <new>
+
 #include <cmath>
 #include <cstdint>
 #include <string>
@@ -87,7 +89,7 @@ extern "C" {
 const char* dptm_sasa_last_error(void) { return g_sasa_err.c_str(); }
 
 int dptm_sasa(const double* xyz, const double* radii, int64_t n, double probe, const double* unit_points, int32_t n_points,
-              int32_t device, double* area_out) {
+              int32_t device, double* area_out) try {
     auto fail = [](int code, const std::string& msg) {
         g_sasa_err = msg;
         return code;
@@ -96,38 +98,45 @@ int dptm_sasa(const double* xyz, const double* radii, int64_t n, double probe, c
     if (n == 0) return DPTM_OK;
     if (!xyz || !radii || !unit_points || !area_out) return fail(DPTM_EINVAL, "dptm_sasa: NULL buffer");
     if (hipSetDevice(device) != hipSuccess) return fail(DPTM_EINVAL, "dptm_sasa: no such device");
-    double *d_xyz = nullptr, *d_r = nullptr, *d_u = nullptr, *d_a = nullptr;
-    int* d_over = nullptr;
-    auto cleanup = [&]() {
-        for (void* p : {(void*)d_xyz, (void*)d_r, (void*)d_u, (void*)d_a, (void*)d_over})
-            if (p) (void)hipFree(p);
-    };
+    // device buffers of this call, freed on every way out
+    struct DevBufs {
+        void* p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        ~DevBufs() {
+            for (void* q : p)
+                if (q) (void)hipFree(q);
+        }
+    } buf;
+    const size_t bytes[5] = {(size_t)n * 3 * sizeof(double), (size_t)n * sizeof(double), (size_t)n_points * 3 * sizeof(double),
+                             (size_t)n * sizeof(double), sizeof(int)};
+    for (int i = 0; i < 5; ++i) {
+        const hipError_t e = hipMalloc(&buf.p[i], bytes[i]);
+        if (e != hipSuccess) return fail(DPTM_ENOMEM, std::string("dptm_sasa: hipMalloc: ") + hipGetErrorString(e));
+    }
+    double* d_xyz = static_cast<double*>(buf.p[0]);
+    double* d_r = static_cast<double*>(buf.p[1]);
+    double* d_u = static_cast<double*>(buf.p[2]);
+    double* d_a = static_cast<double*>(buf.p[3]);
+    int* d_over = static_cast<int*>(buf.p[4]);
     auto check = [&](hipError_t e, const char* what) {
         if (e == hipSuccess) return true;
         g_sasa_err = std::string("dptm_sasa: ") + what + ": " + hipGetErrorString(e);
-        cleanup();
         return false;
     };
-    if (!check(hipMalloc((void**)&d_xyz, (size_t)n * 3 * sizeof(double)), "hipMalloc")) return DPTM_ENOMEM;
-    if (!check(hipMalloc((void**)&d_r, (size_t)n * sizeof(double)), "hipMalloc")) return DPTM_ENOMEM;
-    if (!check(hipMalloc((void**)&d_u, (size_t)n_points * 3 * sizeof(double)), "hipMalloc")) return DPTM_ENOMEM;
-    if (!check(hipMalloc((void**)&d_a, (size_t)n * sizeof(double)), "hipMalloc")) return DPTM_ENOMEM;
-    if (!check(hipMalloc((void**)&d_over, sizeof(int)), "hipMalloc")) return DPTM_ENOMEM;
-    if (!check(hipMemcpy(d_xyz, xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice), "copy in")) return DPTM_EHIP;
-    if (!check(hipMemcpy(d_r, radii, (size_t)n * sizeof(double), hipMemcpyHostToDevice), "copy in")) return DPTM_EHIP;
-    if (!check(hipMemcpy(d_u, unit_points, (size_t)n_points * 3 * sizeof(double), hipMemcpyHostToDevice), "copy in")) return DPTM_EHIP;
+    if (!check(hipMemcpy(d_xyz, xyz, bytes[0], hipMemcpyHostToDevice), "copy in")) return DPTM_EHIP;
+    if (!check(hipMemcpy(d_r, radii, bytes[1], hipMemcpyHostToDevice), "copy in")) return DPTM_EHIP;
+    if (!check(hipMemcpy(d_u, unit_points, bytes[2], hipMemcpyHostToDevice), "copy in")) return DPTM_EHIP;
     if (!check(hipMemset(d_over, 0, sizeof(int)), "memset")) return DPTM_EHIP;
     hipLaunchKernelGGL(sasa_kernel, dim3((unsigned)n), dim3(kThreads), 0, 0, d_xyz, d_r, (int)n, probe, d_u, (int)n_points, d_a, d_over);
     if (!check(hipGetLastError(), "launch")) return DPTM_EHIP;
     int over = 0;
     if (!check(hipMemcpy(&over, d_over, sizeof(int), hipMemcpyDeviceToHost), "copy out")) return DPTM_EHIP;
-    if (over) {
-        cleanup();
-        return fail(DPTM_EINVAL, "dptm_sasa: an atom has more than 1024 neighbours (coordinates not in Angstrom?)");
-    }
-    if (!check(hipMemcpy(area_out, d_a, (size_t)n * sizeof(double), hipMemcpyDeviceToHost), "copy out")) return DPTM_EHIP;
-    cleanup();
+    if (over) return fail(DPTM_EINVAL, "dptm_sasa: an atom has more than 1024 neighbours (coordinates not in Angstrom?)");
+    if (!check(hipMemcpy(area_out, d_a, bytes[3], hipMemcpyDeviceToHost), "copy out")) return DPTM_EHIP;
     return DPTM_OK;
+} catch (const std::bad_alloc&) {
+    return DPTM_ENOMEM;
+} catch (...) {
+    return DPTM_EHIP;
 }
 
 }  // extern "C"

@@ -4,6 +4,9 @@
 // AdamW update of trainer.py:305-306.  Host code only; kernels are in dptm_train_kernels.hip.
 #include <hip/hip_runtime.h>
 
+#include <memory>
+#include <new>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -361,6 +364,25 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
 
 }  // namespace
 
+// a C++ exception must not leave an extern "C" function (see the function-try-blocks below)
+static int on_texception(const char* where) noexcept {
+    int code = DPTM_EHIP;
+    try {
+        try {
+            throw;
+        } catch (const std::bad_alloc&) {
+            code = DPTM_ENOMEM;
+            g_terr = std::string(where) + ": out of host memory";
+        } catch (const std::exception& e) {
+            g_terr = std::string(where) + ": " + e.what();
+        } catch (...) {
+            g_terr = std::string(where) + ": unknown C++ exception";
+        }
+    } catch (...) {
+    }
+    return code;
+}
+
 extern "C" {
 
 const char* dptm_trainer_last_error(void) { return g_terr.c_str(); }
@@ -388,24 +410,20 @@ void dptm_trainer_destroy(dptm_trainer* t) {
 int64_t dptm_trainer_param_floats(const dptm_trainer* t) { return t ? t->pm.total : 0; }
 
 int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spec, int device, int64_t max_batch,
-                        dptm_trainer** out) {
+                        dptm_trainer** out) try {
     if (!out) return tfail(DPTM_EINVAL, "dptm_trainer_create: out is NULL");
     *out = nullptr;
     if (!weights || max_batch < 1) return tfail(DPTM_EINVAL, "dptm_trainer_create: bad argument");
     if (dptm_weight_count(spec) < 0) return tfail(DPTM_EINVAL, "dptm_trainer_create: unsupported model spec");
     dptm_trainer* t = new (std::nothrow) dptm_trainer();
     if (!t) return tfail(DPTM_ENOMEM, "dptm_trainer_create: out of host memory");
-    t->pm.build();
-    if ((int64_t)(nbytes / sizeof(float)) != t->pm.canon_total) {
-        delete t;
-        return tfail(DPTM_EINVAL, "dptm_trainer_create: weight blob has the wrong size");
-    }
+    std::unique_ptr<dptm_trainer, void (*)(dptm_trainer*)> owner(t, dptm_trainer_destroy);   // released on success only
     t->device = device;
+    t->pm.build();
+    if ((int64_t)(nbytes / sizeof(float)) != t->pm.canon_total)
+        return tfail(DPTM_EINVAL, "dptm_trainer_create: weight blob has the wrong size");
     t->max_batch = max_batch;
-    auto bail = [&](int code, const char* msg) {
-        dptm_trainer_destroy(t);
-        return tfail(code, msg);
-    };
+    auto bail = [&](int code, const char* msg) { return tfail(code, msg); };   // `owner` frees the half-built trainer
     if (hipSetDevice(device) != hipSuccess) return bail(DPTM_EINVAL, "dptm_trainer_create: no such device");
     if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) return bail(DPTM_EHIP, "hipStreamCreate failed");
     for (int b = 0; b < 3; ++b)
@@ -436,22 +454,21 @@ int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spe
     t->arena.cap = arena_bytes(max_batch);
     if (hipMalloc((void**)&t->arena.base, t->arena.cap) != hipSuccess) return bail(DPTM_ENOMEM, "dptm_trainer_create: activation arena");
     int rc = alloc_acts(t);
-    if (rc) {
-        std::string keep = g_terr;
-        dptm_trainer_destroy(t);
-        g_terr = keep;
-        return rc;
-    }
+    if (rc) return rc;
     if (hipDeviceSynchronize() != hipSuccess) return bail(DPTM_EHIP, "dptm_trainer_create: sync");
-    *out = t;
+    *out = owner.release();
     return DPTM_OK;
+} catch (...) {
+    return on_texception("dptm_trainer_create");
 }
 
-int dptm_trainer_grad_buffer(dptm_trainer* t, float** dev_ptr, int64_t* count) {
+int dptm_trainer_grad_buffer(dptm_trainer* t, float** dev_ptr, int64_t* count) try {
     if (!t || !dev_ptr || !count) return tfail(DPTM_EINVAL, "dptm_trainer_grad_buffer: NULL argument");
     *dev_ptr = t->G;
     *count = t->pm.total;
     return DPTM_OK;
+} catch (...) {
+    return on_texception("dptm_trainer_grad_buffer");
 }
 
 // Enqueues forward (training mode) + loss + backward of one local batch on `st`.  No host synchronisation, no
@@ -553,7 +570,7 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
 // stream, and replayed from then on.  Off by default: on this stack eager issue is the faster of the two.
 int dptm_trainer_forward_backward(dptm_trainer* t, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
                                   const float* strct, const float* esm, const int32_t* labels, int64_t n,
-                                  const dptm_train_opts* o, float* loss_out, void* stream) {
+                                  const dptm_train_opts* o, float* loss_out, void* stream) try {
     if (!t || !o) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward: NULL argument");
     if (n < 1 || n > t->max_batch) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward: batch size outside 1..max_batch");
     if (!tok21 || !tok33 || !tok51 || !strct || !esm || !labels) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward: NULL buffer");
@@ -612,10 +629,12 @@ int dptm_trainer_forward_backward(dptm_trainer* t, const uint8_t* tok21, const u
         T_TRY(hipStreamSynchronize(st));
     }
     return DPTM_OK;
+} catch (...) {
+    return on_texception("dptm_trainer_forward_backward");
 }
 
 // tensorflow-addons AdamW step on the flat buffers (gradients are multiplied by grad_scale first).
-int dptm_trainer_apply(dptm_trainer* t, float lr, float weight_decay, float grad_scale, float stat_scale, void* stream) {
+int dptm_trainer_apply(dptm_trainer* t, float lr, float weight_decay, float grad_scale, float stat_scale, void* stream) try {
     if (!t) return tfail(DPTM_EINVAL, "dptm_trainer_apply: NULL trainer");
     T_TRY(hipSetDevice(t->device));
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : t->stream;
@@ -625,6 +644,8 @@ int dptm_trainer_apply(dptm_trainer* t, float lr, float weight_decay, float grad
     T_TRY(t_adamw(t->W, t->G, t->M, t->V, t->trainable, stat_scale, t->pm.total, lr_t, weight_decay, (float)b1, (float)b2, 1e-7f,
                   grad_scale, st));
     return DPTM_OK;
+} catch (...) {
+    return on_texception("dptm_trainer_apply");
 }
 
 static int copy_out(dptm_trainer* t, const float* dev, float* host_canonical) {
@@ -638,20 +659,26 @@ static int copy_out(dptm_trainer* t, const float* dev, float* host_canonical) {
 }
 
 // Weights / gradients in the canonical blob order (host buffers of dptm_weight_count floats).
-int dptm_trainer_get_weights(dptm_trainer* t, float* host_out) {
+int dptm_trainer_get_weights(dptm_trainer* t, float* host_out) try {
     if (!t || !host_out) return tfail(DPTM_EINVAL, "dptm_trainer_get_weights: NULL argument");
     return copy_out(t, t->W, host_out);
+} catch (...) {
+    return on_texception("dptm_trainer_get_weights");
 }
-int dptm_trainer_get_grads(dptm_trainer* t, float* host_out) {
+int dptm_trainer_get_grads(dptm_trainer* t, float* host_out) try {
     if (!t || !host_out) return tfail(DPTM_EINVAL, "dptm_trainer_get_grads: NULL argument");
     return copy_out(t, t->G, host_out);
+} catch (...) {
+    return on_texception("dptm_trainer_get_grads");
 }
-int dptm_trainer_get_proba(dptm_trainer* t, float* host_out, int64_t n) {
+int dptm_trainer_get_proba(dptm_trainer* t, float* host_out, int64_t n) try {
     if (!t || !host_out || n < 0 || n > t->max_batch) return tfail(DPTM_EINVAL, "dptm_trainer_get_proba: bad argument");
     T_TRY(hipSetDevice(t->device));
     T_TRY(hipDeviceSynchronize());
     T_TRY(hipMemcpy(host_out, t->proba, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost));
     return DPTM_OK;
+} catch (...) {
+    return on_texception("dptm_trainer_get_proba");
 }
 
 }  // extern "C"

@@ -73,3 +73,35 @@ def test_model_weights_roundtrip(tmp_path):
         load_model(str(tmp_path / "missing.h5"))
     with pytest.raises(ValueError):
         m.set_weights(ws[:-1])
+
+
+def test_low_level_buffers_are_checked_before_the_c_call():
+    """The C side reads raw memory, so the binding refuses wrong dtypes, shapes and strided views
+    instead of passing their address on (no handle is needed to get that far)."""
+    ok = np.zeros((4, 21), dtype=np.uint8)
+    assert _native._buffer(ok, np.uint8, (4, 21), "t") is ok
+    assert _native._buffer(np.zeros(7, np.uint8), np.uint8, (None,), "t").shape == (7,)
+    with pytest.raises(ValueError, match="dtype"):
+        _native._buffer(ok.astype(np.int64), np.uint8, (4, 21), "t")
+    with pytest.raises(ValueError, match="shape"):
+        _native._buffer(ok, np.uint8, (4, 33), "t")
+    with pytest.raises(ValueError, match="contiguous"):
+        _native._buffer(np.zeros((4, 42), np.uint8)[:, ::2], np.uint8, (4, 21), "t")
+    with pytest.raises(ValueError):
+        _native._buffer([[0] * 21] * 4, np.uint8, (4, 21), "t")
+
+
+def test_null_handles_and_arguments_are_refused():
+    """Entry points that can be reached without a GPU reject NULL handles / arguments with DPTM_EINVAL."""
+    lib = _native.load_library()
+    assert lib.dptm_sync(None) == _native.DPTM_EINVAL
+    assert lib.dptm_set_precision(None, 0) == _native.DPTM_EINVAL
+    assert lib.dptm_score(None, None, None, None, None, None, 4, None) == _native.DPTM_EINVAL
+    assert lib.dptm_score_device(None, None, None, None, None, None, 4, None, None) == _native.DPTM_EINVAL
+    assert lib.dptm_profile_begin(None) == _native.DPTM_EINVAL
+    assert b"NULL handle" in lib.dptm_last_error()
+    assert lib.dptm_chunk_sites(None) == 0
+    lib.dptm_destroy(None)           # a no-op
+    lib.dptm_trainer_destroy(None)
+    assert lib.dptm_trainer_param_floats(None) == 0
+    assert lib.dptm_create(None, 0, None, 0, None) == _native.DPTM_EINVAL
