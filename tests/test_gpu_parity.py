@@ -97,6 +97,32 @@ def test_rows_independent_and_ordered(model):
     assert np.isfinite(p).all() and np.abs(p.sum(axis=1) - 1).max() < 1e-6
 
 
+def test_full_size_is_periodic_and_matches_oracle(model, weights):
+    """BASELINE config 3 size (1,000,000 sites, device-resident): the inputs are a 7,919-site block
+    repeated (7,919 is prime, so the copies land at every offset of the 5/7/12-site tiles and cross
+    every 32,768-site pass), hence the output must repeat bit for bit; its first rows are checked
+    against the oracle."""
+    import torch
+    dev = torch.device("cuda:0")
+    period, n = 7919, 1_000_000
+    x = spec.synthetic_inputs(period, 4242)
+    reps = -(-n // period)
+    d = [torch.from_numpy(a).to(dev).repeat((reps, 1))[:n].contiguous() for a in x]
+    out = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    model.scorer.score_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+                              n, out.data_ptr(), st)
+    torch.cuda.synchronize()
+    first = out[:period]
+    full = (n // period) * period
+    assert bool((out[:full].view(-1, period, 2) == first).all())
+    assert bool((out[full:] == first[: n - full]).all())
+    p = first.cpu().numpy()
+    assert np.isfinite(p).all() and np.abs(p.sum(axis=1) - 1).max() < 1e-6
+    k = 400
+    assert np.abs(p[:k] - oracle(weights, [a[:k] for a in x])).max() < TOL
+
+
 @pytest.mark.parametrize("pid,tag", [("P31749", "phospho"), ("P31749", "ubiq"), ("P10636", "phospho")])
 def test_shipped_proteins(model, weights, golden_dir, pid, tag):
     g = np.load(os.path.join(golden_dir, "proteins.npz"))
