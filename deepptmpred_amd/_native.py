@@ -30,8 +30,11 @@ EXPORTS = (
     "dptm_set_precision", "dptm_trainer_create", "dptm_trainer_destroy", "dptm_trainer_forward_backward",
     "dptm_trainer_grad_buffer", "dptm_trainer_param_floats", "dptm_trainer_apply",
     "dptm_trainer_get_weights", "dptm_trainer_get_grads", "dptm_trainer_get_proba",
-    "dptm_trainer_last_error", "dptm_sasa", "dptm_sasa_last_error",
+    "dptm_trainer_last_error", "dptm_trainer_set_allreduce", "dptm_sasa", "dptm_sasa_last_error",
 )
+
+# int (*dptm_allreduce_fn)(void* user, float* buf, int64_t count, void* stream)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 
 class NativeLibraryError(RuntimeError):
@@ -156,6 +159,8 @@ def load_library() -> C.CDLL:
         getattr(lib, name).argtypes = [vp, f32p]
     lib.dptm_trainer_get_proba.restype = C.c_int
     lib.dptm_trainer_get_proba.argtypes = [vp, f32p, i64]
+    lib.dptm_trainer_set_allreduce.restype = C.c_int
+    lib.dptm_trainer_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
     lib.dptm_trainer_last_error.restype = C.c_char_p
     lib.dptm_trainer_last_error.argtypes = []
     lib.dptm_sasa.restype = C.c_int
@@ -341,12 +346,34 @@ class Trainer:
         except Exception:
             pass
 
+    def set_allreduce(self, fn) -> None:
+        """``fn(dev_ptr: int, count: int, stream: int)`` must sum ``count`` floats at ``dev_ptr`` over
+        all replicas, ordered on the HIP stream ``stream`` (synchronised BatchNorm); ``None`` turns it
+        off.  An exception raised inside ``fn`` aborts the step and is re-raised by forward_backward."""
+        self._ar_error = None
+        if fn is None:
+            self._ar_cb = ALLREDUCE_FN()            # NULL function pointer
+        else:
+            def trampoline(_user, buf, count, stream):
+                try:
+                    fn(int(buf or 0), int(count), int(stream or 0))
+                    return 0
+                except BaseException as e:           # must not propagate into the C frame
+                    self._ar_error = e
+                    return -1
+            self._ar_cb = ALLREDUCE_FN(trampoline)   # kept alive as long as the trainer uses it
+        _check_t(self._lib, self._lib.dptm_trainer_set_allreduce(self._h, self._ar_cb, None),
+                 "dptm_trainer_set_allreduce")
+
     def forward_backward(self, tok21, tok33, tok51, strct, esm, labels, n, opts: TrainOpts,
                          want_loss: bool = True, stream=0):
         loss = C.c_float(0.0)
         rc = self._lib.dptm_trainer_forward_backward(
             self._h, tok21, tok33, tok51, strct, esm, labels, n, C.byref(opts),
             C.byref(loss) if want_loss else None, C.c_void_p(stream or None))
+        err, self._ar_error = getattr(self, "_ar_error", None), None
+        if err is not None:
+            raise err
         _check_t(self._lib, rc, "dptm_trainer_forward_backward")
         return float(loss.value) if want_loss else None
 

@@ -126,7 +126,7 @@ struct dptm_trainer {
     // the per-site layers, so each owns its gradient scratch ([rows][64] / [rows][256]) and BatchNorm sums.
     struct Scratch {
         float *g64a = nullptr, *g64b = nullptr, *g64c = nullptr, *g64d = nullptr, *g256 = nullptr;
-        float *gq = nullptr, *gk = nullptr, *gv = nullptr, *bnstat = nullptr, *bnsums = nullptr;
+        float *gq = nullptr, *gk = nullptr, *gv = nullptr, *bnstat = nullptr, *bnsums = nullptr, *bnsums_all = nullptr;
     };
     Scratch sc[4];                        // [0..2] sequence branches, [3] per-site layers (BatchNorm sums only)
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
@@ -150,6 +150,10 @@ struct dptm_trainer {
     GraphKey gkey;
     int gkey_hits = 0;                    // consecutive eager calls with gkey
     hipGraphExec_t gexec = nullptr;
+    // synchronised BatchNorm: sums the column sums of every BatchNorm over the replicas (NULL: per-replica statistics)
+    dptm_allreduce_fn ar_fn = nullptr;
+    void* ar_user = nullptr;
+    int64_t n_local = 1, n_global = 1;    // sites of the current call here / over all replicas
     bool use_graph = false;               // opt-in (DPTM_TRAIN_GRAPH=1): replay measures slower than eager multi-stream issue
 };
 
@@ -184,7 +188,7 @@ int alloc_acts(dptm_trainer* t) {
           need(t->proba, B * 2) && need(t->d_loss, 64);
     for (int b = 0; b < 4; ++b) {
         dptm_trainer::Scratch& s = t->sc[b];
-        ok &= need(s.bnstat, 1024) && need(s.bnsums, 1024);
+        ok &= need(s.bnstat, 1024) && need(s.bnsums, 1024) && need(s.bnsums_all, 1024);
         if (b == 3) break;
         const size_t RM = (size_t)B * kW[b];
         ok &= need(s.g64a, RM * 64) && need(s.g64b, RM * 64) && need(s.g64c, RM * 64) && need(s.g64d, RM * 64) &&
@@ -202,7 +206,7 @@ size_t arena_bytes(int64_t B) {
         f += R * 64 * 9 + 2 * (R * 64 * 10 + R * 256 * 2 + R * 2 + (size_t)B * 4 * kW[b] * kW[b]) + R * 64 + R * 2;
     }
     f += (size_t)B * (128 * 2 + 512 * 3 + 256 + 576 + 512 * 3 + 256 * 3 + 2);
-    f += (size_t)B * (21 + 33 + 51) * (64 * 7 + 256) + 8 * 1024 + (size_t)B * (576 + 1024 + 512 + 128);
+    f += (size_t)B * (21 + 33 + 51) * (64 * 7 + 256) + 12 * 1024 + (size_t)B * (576 + 1024 + 512 + 128);
     return f * sizeof(float) + (size_t)640 * 256 + (1 << 20);   // + per-allocation rounding slack
 }
 
@@ -216,13 +220,43 @@ struct Ctx {
     float* g(int id) const { return G + t->pm.t[id].off; }
 };
 
+// rows of the whole (all-replica) batch that correspond to `rows` local rows
+int64_t global_rows(const dptm_trainer* t, int64_t rows) { return t->ar_fn ? rows / t->n_local * t->n_global : rows; }
+
+int replica_sum(const Ctx& c, float* buf, int64_t count) {
+    if (!c.t->ar_fn) return DPTM_OK;
+    if (c.t->ar_fn(c.t->ar_user, buf, count, c.st) != 0)
+        return tfail(DPTM_EHIP, "dptm_trainer_forward_backward: the all-reduce callback reported an error");
+    return DPTM_OK;
+}
+
 // BatchNorm in training mode on y [rows][cols] -> z (may live inside a wider buffer)
 int bn_train_fwd(const Ctx& c, const float* y, float* z, int64_t ldz, int zoff, int64_t rows, int cols, const BnP& bn, float* mi) {
     T_TRY(hipMemsetAsync(c.s->bnstat, 0, 2 * cols * sizeof(float), c.st));
     T_TRY(t_colsum2(y, nullptr, rows, cols, c.s->bnstat, c.st));
+    int rc = replica_sum(c, c.s->bnstat, 2 * cols);
+    if (rc) return rc;
     // the batch statistics ride in the (otherwise unused) moving-stat slots of the gradient buffer
-    T_TRY(t_bn_finalize(c.s->bnstat, cols, rows, mi, c.g(bn.mean), c.g(bn.var), c.st));
+    T_TRY(t_bn_finalize(c.s->bnstat, cols, global_rows(c.t, rows), mi, c.g(bn.mean), c.g(bn.var), c.st));
     T_TRY(t_bn_fwd(y, z, rows, cols, mi, c.w(bn.gamma), c.w(bn.beta), ldz, zoff, c.st));
+    return DPTM_OK;
+}
+
+// Backward of the same layer: dz (inside a wider buffer) -> dy, gamma / beta gradients accumulated.  The
+// input gradient needs the sums over the WHOLE batch, the parameter gradients this replica's share only
+// (the gradient all-reduce adds the shares up).
+int bn_train_bwd(const Ctx& c, const float* dz, int64_t lddz, int dzoff, const float* y, float* dy, int64_t rows, int cols,
+                 const float* mi, const BnP& bn) {
+    T_TRY(t_bn_bwd_reduce(dz, lddz, dzoff, y, rows, cols, mi, c.s->bnsums, c.st));
+    const float* all = c.s->bnsums;
+    if (c.t->ar_fn) {
+        T_TRY(hipMemcpyAsync(c.s->bnsums_all, c.s->bnsums, 2 * cols * sizeof(float), hipMemcpyDeviceToDevice, c.st));
+        int rc = replica_sum(c, c.s->bnsums_all, 2 * cols);
+        if (rc) return rc;
+        all = c.s->bnsums_all;
+    }
+    T_TRY(t_bn_bwd_apply(dz, lddz, dzoff, y, dy, rows, cols, mi, c.w(bn.gamma), all, global_rows(c.t, rows), c.s->bnsums,
+                         c.g(bn.gamma), c.g(bn.beta), c.st));
     return DPTM_OK;
 }
 
@@ -349,11 +383,11 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
     }
     // conv block: x1 = BN2(swish(conv3b(z1))) + conv1(x0); dx = d(x1)
     // BatchNorm 2 -> dY2 (tmp) -> dA2 (tmp)
-    T_TRY(t_bn_bwd(dx, 64, 0, a.y2, tmp, R, 64, a.mi2, c.w(p.bn2.gamma), c.s->bnsums, c.g(p.bn2.gamma), c.g(p.bn2.beta), c.st));
+    if ((rc = bn_train_bwd(c, dx, 64, 0, a.y2, tmp, R, 64, a.mi2, p.bn2))) return rc;
     T_TRY(t_swish_bwd(a.a2, tmp, tmp, R64, c.st));
     if ((rc = conv_bwd(c, a.z1, tmp, p.c3bk, p.c3bb, 3, dsum, false, R, wl))) return rc;     // dsum = dZ1 (after dropout)
     T_TRY(t_dropout(dsum, R, 64, 64, wl, seed, b * 8 + 1, rt.conv, c.st));
-    T_TRY(t_bn_bwd(dsum, 64, 0, a.y1, tmp, R, 64, a.mi1, c.w(p.bn1.gamma), c.s->bnsums, c.g(p.bn1.gamma), c.g(p.bn1.beta), c.st));
+    if ((rc = bn_train_bwd(c, dsum, 64, 0, a.y1, tmp, R, 64, a.mi1, p.bn1))) return rc;
     T_TRY(t_swish_bwd(a.a1, tmp, tmp, R64, c.st));                                          // dA1
     if ((rc = conv_bwd(c, a.x0, tmp, p.c3ak, p.c3ab, 3, dh, false, R, wl))) return rc;       // dh = dX0 from conv3a
     if ((rc = conv_bwd(c, a.x0, dx, p.sck, p.scb, 1, dh, true, R, wl))) return rc;           // += shortcut path
@@ -523,12 +557,12 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
                       c.g(pm.head.k), c.g(pm.head.b), st));
     // ---------------- backward, per-site layers
     // trunk 2: BN -> swish -> dense
-    T_TRY(t_bn_bwd(t->d256a, 256, 0, t->t2y, t->d256b, B, 256, t->t2mi, c.w(pm.t2.bn.gamma), c.s->bnsums, c.g(pm.t2.bn.gamma), c.g(pm.t2.bn.beta), st));
+    if ((rc = bn_train_bwd(c, t->d256a, 256, 0, t->t2y, t->d256b, B, 256, t->t2mi, pm.t2.bn))) return rc;
     T_TRY(t_swish_bwd(t->t2a, t->d256b, t->d256b, B * 256, st));
     T_TRY(t_gemm_tn(gt(t->t1z, 512, 0, t->d256b, 256, 0, c.g(pm.t2.k), 256, c.g(pm.t2.b), B, 512, 256), st));
     T_TRY(t_gemm(ga(t->d256b, 256, c.w(pm.t2.k), 256, nullptr, t->d512a, 512, 0, B, 256, 512), true, st));
     T_TRY(t_dropout(t->d512a, B, 512, 512, 0, seed, 24 + 3, rt.dense, st));
-    T_TRY(t_bn_bwd(t->d512a, 512, 0, t->t1y, t->d512b, B, 512, t->t1mi, c.w(pm.t1.bn.gamma), c.s->bnsums, c.g(pm.t1.bn.gamma), c.g(pm.t1.bn.beta), st));
+    if ((rc = bn_train_bwd(c, t->d512a, 512, 0, t->t1y, t->d512b, B, 512, t->t1mi, pm.t1.bn))) return rc;
     T_TRY(t_swish_bwd(t->t1a, t->d512b, t->d512b, B * 512, st));
     T_TRY(t_gemm_tn(gt(t->concat, kConcat, 0, t->d512b, 512, 0, c.g(pm.t1.k), 512, c.g(pm.t1.b), B, kConcat, 512), st));
     T_TRY(t_gemm(ga(t->d512b, 512, c.w(pm.t1.k), 512, nullptr, t->dconcat, kConcat, 0, B, 512, kConcat), true, st));
@@ -539,13 +573,13 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
     T_TRY(t_gemm_tn(gt(t->e1, 512, 0, t->d256a, 256, 0, c.g(pm.esm2.k), 256, c.g(pm.esm2.b), B, 512, 256), st));
     T_TRY(t_gemm(ga(t->d256a, 256, c.w(pm.esm2.k), 256, nullptr, t->d512a, 512, 0, B, 256, 512), true, st));
     T_TRY(t_dropout(t->d512a, B, 512, 512, 0, seed, 24 + 1, rt.dense, st));
-    T_TRY(t_bn_bwd(t->d512a, 512, 0, t->ey, t->d512b, B, 512, t->emi, c.w(pm.esm1.bn.gamma), c.s->bnsums, c.g(pm.esm1.bn.gamma), c.g(pm.esm1.bn.beta), st));
+    if ((rc = bn_train_bwd(c, t->d512a, 512, 0, t->ey, t->d512b, B, 512, t->emi, pm.esm1.bn))) return rc;
     T_TRY(t_swish_bwd(t->ea, t->d512b, t->d512b, B * 512, st));
     T_TRY(t_gemm_tn(gt(esm, kEsm, 0, t->d512b, 512, 0, c.g(pm.esm1.k), 512, c.g(pm.esm1.b), B, kEsm, 512), st));
     // struct branch: d(concat[:,192:320]) -> dropout -> BN -> swish -> dense
     T_TRY(t_copy_cols(t->d128, 128, 0, t->dconcat, kConcat, 192, B, 128, false, st));
     T_TRY(t_dropout(t->d128, B, 128, 128, 0, seed, 24 + 0, rt.dense, st));
-    T_TRY(t_bn_bwd(t->d128, 128, 0, t->sy, t->d512a, B, 128, t->smi, c.w(pm.strct.bn.gamma), c.s->bnsums, c.g(pm.strct.bn.gamma), c.g(pm.strct.bn.beta), st));
+    if ((rc = bn_train_bwd(c, t->d128, 128, 0, t->sy, t->d512a, B, 128, t->smi, pm.strct.bn))) return rc;
     T_TRY(t_swish_bwd(t->sa, t->d512a, t->d512a, B * 128, st));
     T_TRY(t_gemm_tn(gt(strct, 8, 0, t->d512a, 128, 0, c.g(pm.strct.k), 128, c.g(pm.strct.b), B, 8, 128), st));
     // sequence branches, again side by side (d(concat) is complete; each branch owns its parameters' gradients)
@@ -577,6 +611,8 @@ int dptm_trainer_forward_backward(dptm_trainer* t, const uint8_t* tok21, const u
     T_TRY(hipSetDevice(t->device));
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : t->stream;
     const float ng = o->n_global > 0 ? (float)o->n_global : (float)n;
+    t->n_local = n;
+    t->n_global = o->n_global > 0 ? o->n_global : n;
     T_TRY(t_set_step(t->d_step, o->seed, ng, (float)o->n_pos_global, st));
     dptm_trainer::GraphKey key;
     key.n = n;
@@ -588,7 +624,11 @@ int dptm_trainer_forward_backward(dptm_trainer* t, const uint8_t* tok21, const u
     key.l2_scale = o->l2_scale;
     key.st = st;
     int rc = DPTM_OK;
-    if (t->use_graph && t->gexec && key == t->gkey) {
+    if (t->ar_fn) {
+        // the callback runs on the host between launches, so this sequence is never captured into a graph
+        rc = enqueue_forward_backward(t, tok21, tok33, tok51, strct, esm, labels, n, o, st);
+        if (rc) return rc;
+    } else if (t->use_graph && t->gexec && key == t->gkey) {
         T_TRY(hipGraphLaunch(t->gexec, st));
     } else {
         if (!(key == t->gkey)) {
@@ -631,6 +671,15 @@ int dptm_trainer_forward_backward(dptm_trainer* t, const uint8_t* tok21, const u
     return DPTM_OK;
 } catch (...) {
     return on_texception("dptm_trainer_forward_backward");
+}
+
+int dptm_trainer_set_allreduce(dptm_trainer* t, dptm_allreduce_fn fn, void* user) try {
+    if (!t) return tfail(DPTM_EINVAL, "dptm_trainer_set_allreduce: NULL trainer");
+    t->ar_fn = fn;
+    t->ar_user = user;
+    return DPTM_OK;
+} catch (...) {
+    return on_texception("dptm_trainer_set_allreduce");
 }
 
 // tensorflow-addons AdamW step on the flat buffers (gradients are multiplied by grad_scale first).

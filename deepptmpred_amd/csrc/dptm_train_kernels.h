@@ -62,8 +62,11 @@ hipError_t t_bn_finalize(const float* stats, int cols, int64_t rows, float* mean
                          float* batch_var, hipStream_t st);
 hipError_t t_bn_fwd(const float* y, float* z, int64_t rows, int cols, const float* mean_inv, const float* gamma,
                     const float* beta, int64_t ldz, int z_col_off, hipStream_t st);
-hipError_t t_bn_bwd(const float* dz, int64_t lddz, int dz_col_off, const float* y, float* dy, int64_t rows, int cols,
-                    const float* mean_inv, const float* gamma, float* sums, float* dgamma, float* dbeta, hipStream_t st);
+hipError_t t_bn_bwd_reduce(const float* dz, int64_t lddz, int dz_col_off, const float* y, int64_t rows, int cols,
+                           const float* mean_inv, float* sums, hipStream_t st);
+hipError_t t_bn_bwd_apply(const float* dz, int64_t lddz, int dz_col_off, const float* y, float* dy, int64_t rows, int cols,
+                          const float* mean_inv, const float* gamma, const float* sums, int64_t rows_global,
+                          const float* own_sums, float* dgamma, float* dbeta, hipStream_t st);
 hipError_t t_ln_fwd(const float* a, const float* b, const float* g, const float* beta, float* out, float* xhat,
                     float* inv, int64_t rows, hipStream_t st);
 hipError_t t_ln_bwd(const float* dy, const float* xhat, const float* inv, const float* g, float* dsum, float* dg,

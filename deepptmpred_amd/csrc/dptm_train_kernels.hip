@@ -313,12 +313,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
 }
 
-// dy = gamma*inv * (dz - sum_dz/M - xhat * sum_dz_xhat/M); also dgamma += sum_dz_xhat, dbeta += sum_dz
-// (the parameter gradients are added by the first block only)
+// dy = gamma*inv * (dz - sum_dz/M - xhat * sum_dz_xhat/M) with the sums (and M) of the whole batch; also
+// dgamma += sum_dz_xhat, dbeta += sum_dz from own_sums, this replica's share (the parameter gradients are
+// added by the first block only).  On one device sums == own_sums.
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, int64_t lddz, int dz_col_off, const float* __restrict__ y,
                                     float* __restrict__ dy, int64_t rows, int cols, const float* __restrict__ mean_inv,
                                     const float* __restrict__ gamma, const float* __restrict__ sums, float inv_rows,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                    const float* __restrict__ own_sums, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta) {
     const int64_t total = rows * cols;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / cols;
@@ -327,8 +329,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, int64_t lddz, 
         const float xh = (y[i] - mean_inv[c]) * inv;
         dy[i] = gamma[c] * inv * (dz[r * lddz + dz_col_off + c] - sums[c] * inv_rows - xh * sums[cols + c] * inv_rows);
         if (i < cols) {
-            atomicAdd(dgamma + c, sums[cols + c]);
-            atomicAdd(dbeta + c, sums[c]);
+            atomicAdd(dgamma + c, own_sums[cols + c]);
+            atomicAdd(dbeta + c, own_sums[c]);
         }
     }
 }
@@ -772,16 +774,21 @@ hipError_t t_bn_fwd(const float* y, float* z, int64_t rows, int cols, const floa
     if (rows) hipLaunchKernelGGL(bn_fwd_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, st, y, z, rows, cols, mean_inv, gamma, beta, ldz, z_col_off);
     return hipGetLastError();
 }
-hipError_t t_bn_bwd(const float* dz, int64_t lddz, int dz_col_off, const float* y, float* dy, int64_t rows, int cols,
-                    const float* mean_inv, const float* gamma, float* sums, float* dgamma, float* dbeta, hipStream_t st) {
-    if (rows == 0) return hipSuccess;
+hipError_t t_bn_bwd_reduce(const float* dz, int64_t lddz, int dz_col_off, const float* y, int64_t rows, int cols,
+                           const float* mean_inv, float* sums, hipStream_t st) {
     hipError_t e = hipMemsetAsync(sums, 0, 2 * cols * sizeof(float), st);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || rows == 0) return e;
     const int rpb = rows_per_block_for(rows);
     dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + rpb - 1) / rpb));
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, st, dz, lddz, dz_col_off, y, rows, cols, mean_inv, sums, rpb);
+    return hipGetLastError();
+}
+hipError_t t_bn_bwd_apply(const float* dz, int64_t lddz, int dz_col_off, const float* y, float* dy, int64_t rows, int cols,
+                          const float* mean_inv, const float* gamma, const float* sums, int64_t rows_global,
+                          const float* own_sums, float* dgamma, float* dbeta, hipStream_t st) {
+    if (rows == 0) return hipSuccess;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, st, dz, lddz, dz_col_off, y, dy, rows,
-                       cols, mean_inv, gamma, sums, 1.0f / (float)rows, dgamma, dbeta);
+                       cols, mean_inv, gamma, sums, 1.0f / (float)rows_global, own_sums, dgamma, dbeta);
     return hipGetLastError();
 }
 hipError_t t_ln_fwd(const float* a, const float* b, const float* g, const float* beta, float* out, float* xhat,

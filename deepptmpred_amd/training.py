@@ -9,7 +9,8 @@ data-parallel exchange (one process per GPU):
 
   1. all-reduce (sum) of ``[N, N_pos]`` so every replica weights its samples with the
      GLOBAL batch counts the single-device loss definition uses (trainer.py:39-44);
-  2. local forward/backward (BatchNorm normalises with the replica's own batch statistics);
+  2. local forward/backward (BatchNorm normalises with the replica's own batch statistics, or --
+     ``sync_batchnorm=True`` -- with the global batch's: 20 more small all-reduces per step);
   3. ONE all-reduce (sum) over the flat fp32 gradient buffer: every tensor's gradient in
      one bucket, with the batch mean/variance of every BatchNorm riding in the slots of
      its (untrained) moving statistics;
@@ -119,6 +120,34 @@ class NativeBackend:
                                              d[4].data_ptr(), lab.data_ptr(), len(labels), o, True, st)
         return loss
 
+    def enable_sync_batchnorm(self, group=None) -> None:
+        """Every BatchNorm then normalises with the statistics of the GLOBAL batch: its column sums are
+        all-reduced over ``group`` (RCCL on GPUs) inside the step, on the stream the layer runs on, so
+        N replicas reproduce a one-device run on the whole batch.  20 small collectives per step."""
+        import torch.distributed as dist
+        t = self.torch
+        views = {}
+
+        on_device = dist.get_backend(group) == "nccl"     # RCCL reduces device memory in stream order
+
+        def allreduce(ptr: int, count: int, stream: int) -> None:
+            v = views.get((ptr, count))
+            if v is None:
+                v = views[(ptr, count)] = self._wrap(ptr, count)
+            s = t.cuda.ExternalStream(stream, device=self.device) if stream else t.cuda.default_stream(self.device)
+            with t.cuda.stream(s):
+                if on_device:
+                    dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+                else:                                      # host backends (gloo): through host memory
+                    h = v.cpu()                            # waits for the sums on this stream
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                    v.copy_(h)
+
+        self.trainer.set_allreduce(allreduce)
+
+    def disable_sync_batchnorm(self) -> None:
+        self.trainer.set_allreduce(None)
+
     def allreduce_grads(self, group=None) -> None:
         import torch.distributed as dist
         dist.all_reduce(self._grad_view, op=dist.ReduceOp.SUM, group=group)
@@ -138,8 +167,10 @@ class DataParallelTrainer:
     same arrays and scores its own contiguous shard (``shard_range``)."""
 
     def __init__(self, backend, optimizer: AdamW = AdamW(), rates: DropoutRates = DropoutRates(),
-                 l2: float = 1e-4, group=None):
+                 l2: float = 1e-4, group=None, sync_batchnorm: bool = False):
         self.backend = backend
+        if sync_batchnorm:
+            backend.enable_sync_batchnorm(group)
         self.optimizer = optimizer
         self.rates = rates
         self.l2 = l2

@@ -225,6 +225,18 @@ int64_t dptm_trainer_param_floats(const dptm_trainer* t);
 int dptm_trainer_apply(dptm_trainer* t, float lr, float weight_decay, float grad_scale,
                        float stat_scale, void* stream);
 
+/* Synchronised BatchNorm for data-parallel jobs (no counterpart in the reference, which trains on
+ * one device: trainer.py:332).  By default every replica normalises with the statistics of its own
+ * shard.  With a callback set, forward_backward hands it every BatchNorm's column sums -- forward:
+ * [sum x | sum x^2], backward: [sum dz | sum dz*xhat], `count` floats at DEVICE address `buf` --
+ * right after the kernel that produced them was enqueued on `stream` (a hipStream_t).  The callback
+ * must sum the buffer in place over all replicas, ordered on that stream (e.g. an RCCL all-reduce),
+ * and return 0; every replica makes the same sequence of calls (20 per step).  The layer then uses
+ * the GLOBAL batch (opts->n_global sites) for mean, variance and the backward terms, so N replicas
+ * reproduce one device run on the whole batch.  fn = NULL restores per-replica statistics. */
+typedef int (*dptm_allreduce_fn)(void* user, float* buf, int64_t count, void* stream);
+int dptm_trainer_set_allreduce(dptm_trainer* t, dptm_allreduce_fn fn, void* user);
+
 /* Host copies in the canonical blob order (dptm_weight_count floats); they wait for the GPU. */
 int dptm_trainer_get_weights(dptm_trainer* t, float* host_out);
 int dptm_trainer_get_grads(dptm_trainer* t, float* host_out);

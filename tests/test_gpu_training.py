@@ -147,3 +147,62 @@ def test_fit_with_validation_and_reference_callbacks(tmp_path):
         assert np.abs(m.predict(va) - p_best).max() < 1e-6
     best.close()
     m.close()
+
+
+def _sync_bn_worker(rank, world, port, q, backend):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    from deepptmpred_amd.training import AdamW, DataParallelTrainer, DropoutRates, NativeBackend
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    if backend:
+        kw = {"device_id": torch.device("cuda:0")} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    w = spec.synthetic_weights(7)
+    x = spec.synthetic_inputs(24, 9)
+    y = (np.arange(24) % 5 == 0).astype(np.int64)
+    dp = DataParallelTrainer(NativeBackend(w, max_batch=24), AdamW(5e-4, 1e-4), DropoutRates.off(),
+                             sync_batchnorm=bool(backend))
+    losses = [dp.train_on_batch(x, np.eye(2)[y], seed=3 + i) for i in range(2)]
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put((losses, {k: np.asarray(v) for k, v in dp.backend.weights().items()}))
+    if backend:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_replicas_with_synchronised_batchnorm_equal_one_device():
+    """With the BatchNorm column sums all-reduced inside the step, two replicas on half the batch
+    each must reproduce the one-device run on the whole batch: same loss, same weights after two
+    AdamW steps (dropout off; fp32 sums in a different order, hence the small tolerance).  The two
+    replicas share GPU 0, which RCCL refuses, so they talk through gloo (sums staged through host
+    memory); the RCCL form of the callback -- an all-reduce on the layer's own stream -- is
+    exercised with a one-rank group, where it must change nothing."""
+    import multiprocessing as mp
+    import socket
+    ctx = mp.get_context("spawn")
+    results = []
+    for world, backend in ((1, None), (2, "gloo"), (1, "nccl")):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_sync_bn_worker, args=(r, world, port, q, backend)) for r in range(world)]
+        for p in procs:
+            p.start()
+        results.append(q.get(timeout=150))
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    loss1, w1 = results[0]
+    for (loss2, w2), label in zip(results[1:], ("two gloo replicas", "one-rank RCCL group")):
+        assert np.allclose(loss1, loss2, rtol=2e-5, atol=1e-6), (label, loss1, loss2)
+        worst = max(float(np.abs(w1[k] - w2[k]).max()) for k in w1)
+        print("one device vs", label, ": max weight difference", worst)
+        assert worst < 1e-4, label      # Adam divides by |g|: float-atomic noise on a near-zero gradient moves a weight by a fraction of lr = 5e-4
