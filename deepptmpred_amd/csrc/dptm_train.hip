@@ -154,6 +154,7 @@ struct dptm_trainer {
     dptm_allreduce_fn ar_fn = nullptr;
     void* ar_user = nullptr;
     int64_t n_local = 1, n_global = 1;    // sites of the current call here / over all replicas
+    bool serial = false;                  // DPTM_TRAIN_SERIAL=1: branches on the caller's stream too (per-kernel profiling)
     bool use_graph = false;               // opt-in (DPTM_TRAIN_GRAPH=1): replay measures slower than eager multi-stream issue
 };
 
@@ -474,6 +475,7 @@ int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spe
         hipMalloc((void**)&t->d_step, kStepParams * sizeof(unsigned)) != hipSuccess)
         return bail(DPTM_ENOMEM, "dptm_trainer_create: parameter buffers");
     if (const char* env = std::getenv("DPTM_TRAIN_GRAPH")) t->use_graph = std::strcmp(env, "0") != 0;
+    if (const char* env = std::getenv("DPTM_TRAIN_SERIAL")) t->serial = std::strcmp(env, "0") != 0;
     std::vector<float> host((size_t)t->pm.total, 0.0f);
     std::vector<uint8_t> tr((size_t)t->pm.total, 0);
     const float* src = static_cast<const float*>(weights);
@@ -522,10 +524,11 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
     // ---------------- forward: the three sequence branches on side streams, the per-site layers on `st`
     T_TRY(hipEventRecord(t->ev_fork[0], st));
     for (int b = 0; b < 3; ++b) {
-        T_TRY(hipStreamWaitEvent(t->aux[b], t->ev_fork[0], 0));
-        Ctx cb{t, t->aux[b], t->W, t->G, &t->sc[b]};
+        hipStream_t bs = t->serial ? st : t->aux[b];
+        T_TRY(hipStreamWaitEvent(bs, t->ev_fork[0], 0));
+        Ctx cb{t, bs, t->W, t->G, &t->sc[b]};
         if ((rc = branch_fwd(cb, b, tok[b], B, seed, rt))) return rc;
-        T_TRY(hipEventRecord(t->ev_join[0][b], t->aux[b]));
+        T_TRY(hipEventRecord(t->ev_join[0][b], bs));
     }
     // struct branch (model.py:187-189)
     T_TRY(t_gemm(ga(strct, 8, c.w(pm.strct.k), 128, c.w(pm.strct.b), t->sa, 128, 0, B, 8, 128), false, st));
@@ -585,10 +588,11 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
     // sequence branches, again side by side (d(concat) is complete; each branch owns its parameters' gradients)
     T_TRY(hipEventRecord(t->ev_fork[1], st));
     for (int b = 0; b < 3; ++b) {
-        T_TRY(hipStreamWaitEvent(t->aux[b], t->ev_fork[1], 0));
-        Ctx cb{t, t->aux[b], t->W, t->G, &t->sc[b]};
+        hipStream_t bs = t->serial ? st : t->aux[b];
+        T_TRY(hipStreamWaitEvent(bs, t->ev_fork[1], 0));
+        Ctx cb{t, bs, t->W, t->G, &t->sc[b]};
         if ((rc = branch_bwd(cb, b, tok[b], B, seed, rt))) return rc;
-        T_TRY(hipEventRecord(t->ev_join[1][b], t->aux[b]));
+        T_TRY(hipEventRecord(t->ev_join[1][b], bs));
     }
     for (int b = 0; b < 3; ++b) T_TRY(hipStreamWaitEvent(st, t->ev_join[1][b], 0));
     // l2 kernel regularisers (model.py:130-138,200,204): value into the loss, 2*lambda*w into the gradient

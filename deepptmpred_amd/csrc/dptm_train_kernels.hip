@@ -398,10 +398,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 
 // One wavefront per (sample, head).  q,k,v,o: [rows][64] with head hd in columns 16hd..;
 // prob: [samples][4][wlen][wlen].   (model.py:67-82)
+// Lane = query row.  The score row lives in LDS (row stride 53: conflict-free for row-per-lane access)
+// until it is normalised; the probabilities then leave as one linear, coalesced copy.
 __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, float* __restrict__ o,
                                                       float* __restrict__ prob, int wlen) {
-    __shared__ float sk[51][17], sv[51][17];
+    __shared__ float sk[51][17], sv[51][17], sp[51][53];
     const int b = blockIdx.x >> 2, hd = blockIdx.x & 3, lane = threadIdx.x;
     const int64_t base = (int64_t)b * wlen;
     for (int i = lane; i < wlen * 16; i += 64) {
@@ -410,37 +412,41 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
         sv[t][f] = v[(base + t) * 64 + 16 * hd + f];
     }
     __syncthreads();
-    if (lane >= wlen) return;
-    float qr[16];
+    if (lane < wlen) {
+        float qr[16];
 #pragma unroll
-    for (int f = 0; f < 16; ++f) qr[f] = q[(base + lane) * 64 + 16 * hd + f] * 0.25f;
-    float* pr = prob + (((int64_t)b * 4 + hd) * wlen + lane) * wlen;
-    float m = -3.0e38f;
-    for (int t = 0; t < wlen; ++t) {
-        float s = 0.f;
+        for (int f = 0; f < 16; ++f) qr[f] = q[(base + lane) * 64 + 16 * hd + f] * 0.25f;
+        float* pr = sp[lane];
+        float m = -3.0e38f;
+        for (int t = 0; t < wlen; ++t) {
+            float s = 0.f;
 #pragma unroll
-        for (int f = 0; f < 16; ++f) s = fmaf(qr[f], sk[t][f], s);
-        pr[t] = s;
-        m = fmaxf(m, s);
+            for (int f = 0; f < 16; ++f) s = fmaf(qr[f], sk[t][f], s);
+            pr[t] = s;
+            m = fmaxf(m, s);
+        }
+        float den = 0.f;
+        for (int t = 0; t < wlen; ++t) {
+            const float e = __expf(pr[t] - m);
+            pr[t] = e;
+            den += e;
+        }
+        const float rd = 1.0f / den;
+        float acc[16];
+#pragma unroll
+        for (int f = 0; f < 16; ++f) acc[f] = 0.f;
+        for (int t = 0; t < wlen; ++t) {
+            const float p_ = pr[t] * rd;
+            pr[t] = p_;
+#pragma unroll
+            for (int f = 0; f < 16; ++f) acc[f] = fmaf(p_, sv[t][f], acc[f]);
+        }
+#pragma unroll
+        for (int f = 0; f < 16; ++f) o[(base + lane) * 64 + 16 * hd + f] = acc[f];
     }
-    float den = 0.f;
-    for (int t = 0; t < wlen; ++t) {
-        const float e = __expf(pr[t] - m);
-        pr[t] = e;
-        den += e;
-    }
-    const float rd = 1.0f / den;
-    float acc[16];
-#pragma unroll
-    for (int f = 0; f < 16; ++f) acc[f] = 0.f;
-    for (int t = 0; t < wlen; ++t) {
-        const float p_ = pr[t] * rd;
-        pr[t] = p_;
-#pragma unroll
-        for (int f = 0; f < 16; ++f) acc[f] = fmaf(p_, sv[t][f], acc[f]);
-    }
-#pragma unroll
-    for (int f = 0; f < 16; ++f) o[(base + lane) * 64 + 16 * hd + f] = acc[f];
+    __syncthreads();
+    float* pb = prob + ((int64_t)b * 4 + hd) * wlen * wlen;
+    for (int i = lane; i < wlen * wlen; i += 64) pb[i] = sp[i / wlen][i % wlen];
 }
 
 // dq, dk, dv from do (all [rows][64], head columns), with the saved probabilities.
@@ -449,7 +455,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ d_o, float* __restrict__ dq,
                                                       float* __restrict__ dk, float* __restrict__ dv, int wlen) {
     __shared__ float sq[51][17], sk[51][17], sv[51][17], sdo[51][17];
-    __shared__ float sp[51][52], sds[51][52];
+    __shared__ float sp[51][53], sds[51][53];   // odd row stride: row-per-lane and column-per-lane walks are both conflict-free
     const int b = blockIdx.x >> 2, hd = blockIdx.x & 3, lane = threadIdx.x;
     const int64_t base = (int64_t)b * wlen;
     for (int i = lane; i < wlen * 16; i += 64) {
