@@ -266,6 +266,7 @@ GemmArgs ga(const float* x, int64_t ldx, const float* w, int64_t ldw, const floa
     GemmArgs a;
     a.x = x; a.ldx = ldx; a.w = w; a.ldw = ldw; a.bias = bias; a.out = out; a.ldo = ldo; a.col_off = col_off;
     a.m = m; a.k = k; a.cols = cols; a.shift = shift; a.wlen = wlen; a.accumulate = acc;
+    a.taps = 1; a.tap_stride = 0; a.tap_dir = 1;
     return a;
 }
 GemmTnArgs gt(const float* x, int64_t ldx, int xoff, const float* dy, int64_t ldy, int dyoff, float* dw, int64_t ldw, float* db,
@@ -276,13 +277,11 @@ GemmTnArgs gt(const float* x, int64_t ldx, int xoff, const float* dy, int64_t ld
     return a;
 }
 
-// conv1d 'same' as taps: out = sum_t shift_{t-1}(x) * K[t] + b
+// conv1d 'same': out = sum_t shift_{t-1}(x) * K[t] + b, all taps in one product (K is [taps][64][64])
 int conv_fwd(const Ctx& c, const float* x, int kid, int bid, int taps, float* out, int64_t R, int wlen) {
-    for (int tp = 0; tp < taps; ++tp) {
-        const int sh = taps == 1 ? 0 : tp - 1;
-        T_TRY(t_gemm(ga(x, 64, c.w(kid) + (size_t)tp * 64 * 64, 64, tp == 0 ? c.w(bid) : nullptr, out, 64, 0, R, 64, 64, sh, wlen,
-                        tp > 0), false, c.st));
-    }
+    GemmArgs a = ga(x, 64, c.w(kid), 64, c.w(bid), out, 64, 0, R, 64, 64, 0, wlen, 0);
+    a.taps = taps; a.tap_stride = 64 * 64; a.tap_dir = 1;
+    T_TRY(t_gemm(a, false, c.st));
     return DPTM_OK;
 }
 // gradients of a conv: dK[t] += shift(x)^T dout, db += colsum(dout), dx (+)= sum_t shift_{-(t-1)}(dout) K[t]^T
@@ -291,9 +290,11 @@ int conv_bwd(const Ctx& c, const float* x, const float* dout, int kid, int bid, 
         const int sh = taps == 1 ? 0 : tp - 1;
         T_TRY(t_gemm_tn(gt(x, 64, 0, dout, 64, 0, c.g(kid) + (size_t)tp * 64 * 64, 64, tp == 0 ? c.g(bid) : nullptr, R, 64, 64, sh,
                            wlen), c.st));
-        if (dx)
-            T_TRY(t_gemm(ga(dout, 64, c.w(kid) + (size_t)tp * 64 * 64, 64, nullptr, dx, 64, 0, R, 64, 64, -sh, wlen,
-                            (dx_acc || tp > 0) ? 1 : 0), true, c.st));
+    }
+    if (dx) {
+        GemmArgs a = ga(dout, 64, c.w(kid), 64, nullptr, dx, 64, 0, R, 64, 64, 0, wlen, dx_acc ? 1 : 0);
+        a.taps = taps; a.tap_stride = 64 * 64; a.tap_dir = -1;
+        T_TRY(t_gemm(a, true, c.st));
     }
     return DPTM_OK;
 }

@@ -21,6 +21,10 @@ struct GemmArgs {
     int shift;           // input row = output row + shift, inside the same window
     int wlen;            // window length of the row stack (0: rows are independent)
     int accumulate;      // out += result
+    int taps;            // > 1: a 'same' convolution in one pass -- tap t uses the matrix at w + t*tap_stride and the
+                         // row shift tap_dir * (t - taps/2); `shift` is ignored then
+    int64_t tap_stride;
+    int tap_dir;
 };
 
 struct GemmTnArgs {

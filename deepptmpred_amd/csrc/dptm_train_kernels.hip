@@ -54,8 +54,6 @@ __global__ __launch_bounds__(256) void tgemm_kernel(GemmArgs p) {
     if (r0 >= p.m) return;
     const int c0 = blockIdx.y * 64;
     const int64_t r = r0 + j;
-    const bool ok = row_ok(r, p.shift, p.m, p.wlen);
-    const float* xin = p.x + (ok ? (r + p.shift) : 0) * p.ldx + 4 * h;
     f32x16 acc[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -65,35 +63,42 @@ __global__ __launch_bounds__(256) void tgemm_kernel(GemmArgs p) {
             for (int e = 0; e < 4; ++e)
                 acc[t][4 * g + e] = p.bias ? p.bias[c0 + 32 * t + 8 * g + 4 * h + e] : 0.f;
     const int k8 = p.k >> 3;
-    // the contraction is walked in blocks of 64 inputs whose operands are all requested before the first
-    // MFMA of the block: these layers are a few steps deep, so the loads' latency is the cost to hide
-    for (int ub = 0; ub < k8; ub += 8) {
-        f32x4 b[8], a[8][2];
+    const int ntaps = p.taps > 1 ? p.taps : 1;
+    for (int tp = 0; tp < ntaps; ++tp) {
+        const int shift = p.taps > 1 ? p.tap_dir * (tp - p.taps / 2) : p.shift;
+        const float* wm = p.w + tp * p.tap_stride;
+        const bool ok = row_ok(r, shift, p.m, p.wlen);
+        const float* xin = p.x + (ok ? (r + shift) : 0) * p.ldx + 4 * h;
+        // the contraction is walked in blocks of 64 inputs whose operands are all requested before the first
+        // MFMA of the block: these layers are a few steps deep, so the loads' latency is the cost to hide
+        for (int ub = 0; ub < k8; ub += 8) {
+            f32x4 b[8], a[8][2];
 #pragma unroll
-        for (int v = 0; v < 8; ++v) {
-            const int u = ub + v;
-            b[v] = f32x4{0.f, 0.f, 0.f, 0.f};
-            a[v][0] = a[v][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (u < k8) {
-                if (ok) b[v] = *reinterpret_cast<const f32x4*>(xin + 8 * u);
+            for (int v = 0; v < 8; ++v) {
+                const int u = ub + v;
+                b[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+                a[v][0] = a[v][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (u < k8) {
+                    if (ok) b[v] = *reinterpret_cast<const f32x4*>(xin + 8 * u);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int c = c0 + 32 * t + j;
-                    if (NT) {
-                        a[v][t] = *reinterpret_cast<const f32x4*>(p.w + (int64_t)c * p.ldw + 8 * u + 4 * h);
-                    } else {
+                    for (int t = 0; t < 2; ++t) {
+                        const int c = c0 + 32 * t + j;
+                        if (NT) {
+                            a[v][t] = *reinterpret_cast<const f32x4*>(wm + (int64_t)c * p.ldw + 8 * u + 4 * h);
+                        } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) a[v][t][e] = p.w[(int64_t)(8 * u + 4 * h + e) * p.ldw + c];
+                            for (int e = 0; e < 4; ++e) a[v][t][e] = wm[(int64_t)(8 * u + 4 * h + e) * p.ldw + c];
+                        }
                     }
                 }
             }
+#pragma unroll
+            for (int v = 0; v < 8; ++v)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) mfma2(acc[t], a[v][t][e], b[v][e]);
         }
-#pragma unroll
-        for (int v = 0; v < 8; ++v)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) mfma2(acc[t], a[v][t][e], b[v][e]);
     }
     if (r >= p.m) return;
     float* orow = p.out + r * p.ldo + p.col_off + c0 + 4 * h;
@@ -106,6 +111,134 @@ __global__ __launch_bounds__(256) void tgemm_kernel(GemmArgs p) {
             if (p.accumulate) v += *dst;
             *dst = v;
         }
+}
+
+// ------------------------------------------------------------------------------------
+// The same product for large row counts, built around what the first kernel spends its time on: the
+// address unit.  There every wavefront fetches its operands row-per-lane (32 partial cache lines per
+// load) and re-reads the weight tile for every 32 rows.  Here
+//   * the weight tile of the block's 64 output columns (all taps, all of k) is packed ONCE per workgroup
+//     into LDS in MFMA fragment order; a workgroup then walks many row tiles;
+//   * an X tile (32 rows x 64 inputs) arrives with fully coalesced 16-byte loads, requested one segment
+//     ahead, and is turned row-per-lane through a wavefront-private LDS stage;
+//   * the output tile leaves the same way (coalesced, through the stage).
+// A "segment" is one (tap, 64-input block) pair.  Needs k % 64 == 0 and taps * k <= 320 (LDS).
+// grid = (workgroups, cols/64), block 512 = 8 wavefronts, dynamic LDS = taps*k*256 + 8*32*68*4 bytes.
+// ------------------------------------------------------------------------------------
+constexpr int kStageStride = 68;   // floats per staged row: row-per-lane ds_read_b128 is conflict-free
+
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool NT>
+__global__ __launch_bounds__(512) void tgemm_lds_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const int c0 = blockIdx.y * 64;
+    const int ntaps = p.taps > 1 ? p.taps : 1;
+    const int kblocks = p.k >> 6;
+    const int nseg = ntaps * kblocks;
+    f32x4* wl = reinterpret_cast<f32x4*>(lds);                          // [nseg][8][2][64] fragments
+    float* stage = lds + (size_t)nseg * 8 * 2 * 64 * 4 + wave * 32 * kStageStride;
+
+    // ---- weight fragments: element (seg, v, t, lane, e) = Wm_tap(64*kb + 8v + 4h + e, c0 + 32t + j)
+    {
+        float* wf = lds;
+        const int per_seg = 64 * 64;
+        for (int idx = tid; idx < nseg * per_seg; idx += 512) {
+            const int seg = idx / per_seg, rem = idx - seg * per_seg;
+            const int tp = seg / kblocks, kb = seg - tp * kblocks;
+            int kk, cc;           // input index within the 64-block, output column within the 64-tile
+            if (NT) { cc = rem >> 6; kk = rem & 63; } else { kk = rem >> 6; cc = rem & 63; }   // fastest index follows memory
+            const float* wm = p.w + tp * p.tap_stride;
+            const float val = NT ? wm[(int64_t)(c0 + cc) * p.ldw + 64 * kb + kk] : wm[(int64_t)(64 * kb + kk) * p.ldw + c0 + cc];
+            const int v = kk >> 3, hh = (kk >> 2) & 1, e = kk & 3, t = cc >> 5, jj = cc & 31;
+            wf[((((size_t)seg * 8 + v) * 2 + t) * 64 + 32 * hh + jj) * 4 + e] = val;
+        }
+    }
+    __syncthreads();
+
+    const int64_t ntile = (p.m + 31) / 32;
+    // coalesced walk of a 32 x 64 tile: request i of a lane covers row (64 i + lane) / 16, floats 4*((64 i + lane) % 16)..
+    const int crow = lane >> 4, ccol = (lane & 15) * 4;
+    auto fetch = [&](f32x4 (&g)[8], int64_t r0, int seg) {
+        const int tp = seg / kblocks, kb = seg - tp * kblocks;
+        const int shift = p.taps > 1 ? p.tap_dir * (tp - p.taps / 2) : p.shift;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t rr = r0 + 4 * i + crow + shift;
+            g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rr >= 0 && rr < p.m) g[i] = *reinterpret_cast<const f32x4*>(p.x + rr * p.ldx + 64 * kb + ccol);
+        }
+    };
+    for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntile; tile += (int64_t)gridDim.x * 8) {
+        const int64_t r0 = tile * 32;
+        const int64_t r = r0 + j;
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc[t][4 * g + e] = p.bias ? p.bias[c0 + 32 * t + 8 * g + 4 * h + e] : 0.f;
+        f32x4 g[8], gn[8];
+        fetch(g, r0, 0);
+        for (int seg = 0; seg < nseg; ++seg) {
+            if (seg + 1 < nseg) fetch(gn, r0, seg + 1);
+            const int tp = seg / kblocks;
+            const int shift = p.taps > 1 ? p.tap_dir * (tp - p.taps / 2) : p.shift;
+            const bool ok = row_ok(r, shift, p.m, p.wlen);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<f32x4*>(stage + (4 * i + crow) * kStageStride + ccol) = g[i];
+            wave_fence();
+            f32x4 b[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                b[v] = *reinterpret_cast<const f32x4*>(stage + j * kStageStride + 8 * v + 4 * h);
+                if (!ok) b[v] = f32x4{0.f, 0.f, 0.f, 0.f};     // a shifted row outside this row's window
+            }
+            wave_fence();
+            const f32x4* ws = wl + (size_t)seg * 8 * 2 * 64 + lane;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const f32x4 a0 = ws[(v * 2 + 0) * 64], a1 = ws[(v * 2 + 1) * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    mfma2(acc[0], a0[e], b[v][e]);
+                    mfma2(acc[1], a1[e], b[v][e]);
+                }
+            }
+            if (seg + 1 < nseg) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) g[i] = gn[i];
+            }
+        }
+        // ---- output tile through the stage: lane (row j, half h) holds columns 32t + 8g + 4h + e
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                *reinterpret_cast<f32x4*>(stage + j * kStageStride + 32 * t + 8 * gq + 4 * h) =
+                    f32x4{acc[t][4 * gq], acc[t][4 * gq + 1], acc[t][4 * gq + 2], acc[t][4 * gq + 3]};
+        wave_fence();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t rr = r0 + 4 * i + crow;
+            if (rr < p.m) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(stage + (4 * i + crow) * kStageStride + ccol);
+                f32x4* dst = reinterpret_cast<f32x4*>(p.out + rr * p.ldo + p.col_off + c0 + ccol);
+                if (p.accumulate) v += *dst;
+                *dst = v;
+            }
+        }
+        wave_fence();
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -695,6 +828,33 @@ static inline unsigned grid_for(int64_t n, int block = 256, int64_t cap = 256 * 
 hipError_t t_gemm(const GemmArgs& a, bool nt, hipStream_t st) {
     if (a.m == 0) return hipSuccess;
     if (a.cols % 64 != 0 || a.k % 8 != 0) return hipErrorInvalidValue;
+    const int ntaps = a.taps > 1 ? a.taps : 1;
+    // large row stacks whose weight tile fits LDS take the staged kernel; operands must allow 16-byte accesses
+    const bool aligned = a.ldx % 4 == 0 && a.ldo % 4 == 0 && a.col_off % 4 == 0 &&
+                         (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
+    if (a.m >= 4096 && a.k % 64 == 0 && ntaps * a.k <= 320 && aligned) {
+        const size_t lds = (size_t)ntaps * a.k * 256 + (size_t)8 * 32 * kStageStride * sizeof(float);
+        static bool attr_done[64][2] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (!attr_done[dev][nt ? 1 : 0]) {
+            const void* fn = nt ? reinterpret_cast<const void*>(&tgemm_lds_kernel<true>) : reinterpret_cast<const void*>(&tgemm_lds_kernel<false>);
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 320 * 256 + 8 * 32 * kStageStride * 4);
+            if (e != hipSuccess) return e;
+            attr_done[dev][nt ? 1 : 0] = true;
+        }
+        const int64_t tiles8 = (a.m + 255) / 256;
+        const unsigned ycols = (unsigned)(a.cols / 64);
+        int64_t gx = 512 / ycols;                     // about two workgroups per CU over all column tiles
+        if (gx < 1) gx = 1;
+        if (gx > tiles8) gx = tiles8;
+        dim3 grid((unsigned)gx, ycols);
+        if (nt)
+            hipLaunchKernelGGL(tgemm_lds_kernel<true>, grid, dim3(512), lds, st, a);
+        else
+            hipLaunchKernelGGL(tgemm_lds_kernel<false>, grid, dim3(512), lds, st, a);
+        return hipGetLastError();
+    }
     dim3 grid((unsigned)((a.m + 127) / 128), (unsigned)(a.cols / 64));
     if (nt)
         hipLaunchKernelGGL(tgemm_kernel<true>, grid, dim3(256), 0, st, a);

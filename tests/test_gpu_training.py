@@ -42,18 +42,19 @@ def _compare_grads(got_blob, want, label):
     return worst
 
 
-@pytest.mark.parametrize("rates", [(0.0, 0.0, 0.0, 0.0), (1e-4, 0.3, 0.1, 0.3)])
-def test_gradients_match_autograd(rates):
+# 48 sites: the small-batch kernels; 230 sites (4,830 to 11,730 window rows): the LDS-staged matrix products that
+# large row stacks take, with a ragged last row tile
+@pytest.mark.parametrize("rates,n", [((0.0, 0.0, 0.0, 0.0), 48), ((1e-4, 0.3, 0.1, 0.3), 48), ((1e-4, 0.3, 0.1, 0.3), 230)])
+def test_gradients_match_autograd(rates, n):
     import torch
     w = spec.synthetic_weights(7)
-    n = 48
     x = spec.synthetic_inputs(n, 321)
     y = (np.random.default_rng(5).random(n) < 0.25).astype(np.int64)
     ref = TrainRef(w)
     rd = dict(zip(("embed", "conv", "tb", "dense"), rates))
     loss_ref, g_ref = ref.step(x, y, lr=5e-4, weight_decay=1e-4, seed=99, rates=rd)
 
-    tr = _native.Trainer(spec.pack_blob(w), max_batch=64)
+    tr = _native.Trainer(spec.pack_blob(w), max_batch=max(64, n))
     d, lab = _device_batch(x, y)
     loss = tr.forward_backward(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
                                lab.data_ptr(), n, _opts(99, rates, y))
