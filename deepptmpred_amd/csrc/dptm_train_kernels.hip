@@ -285,6 +285,98 @@ __global__ __launch_bounds__(64) void tgemm_tn_kernel(GemmTnArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------
+// The weight gradient for large row stacks: one wavefront owns a whole 64(k) x 64(n) tile of dW (four MFMA
+// tiles, so every operand value read feeds two products) and walks 32-row chunks of its slab.  X and dY
+// chunks arrive with coalesced 16-byte loads, requested one chunk ahead, into wavefront-private LDS stages;
+// rows that fall outside their window after the shift (or past the end) are zeroed as they are staged.
+// The MFMA operands are then single-float LDS reads (lane = k or n index: conflict-free).
+// grid = (k/64, n/64, slabs), block 256 = 4 wavefronts that interleave the slab's chunks.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tgemm_tn_lds_kernel(GemmTnArgs p) {
+    __shared__ __attribute__((aligned(16))) float stage_all[4][2][32 * kStageStride];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, i = lane & 31;
+    const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int64_t rs = (int64_t)blockIdx.z * p.rows_per_slab;
+    const int64_t re = min(p.m, rs + p.rows_per_slab);
+    float* sx = stage_all[wave][0];
+    float* sy = stage_all[wave][1];
+    const int crow = lane >> 4, ccol = (lane & 15) * 4;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum0 = 0.f, bsum1 = 0.f;
+    auto fetch = [&](f32x4 (&gx)[8], f32x4 (&gy)[8], int64_t r0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int64_t r = r0 + 4 * q + crow;
+            gx[q] = gy[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < re) {
+                gy[q] = *reinterpret_cast<const f32x4*>(p.dy + r * p.ldy + p.dy_col_off + n0 + ccol);
+                if (row_ok(r, p.shift, p.m, p.wlen))
+                    gx[q] = *reinterpret_cast<const f32x4*>(p.x + (r + p.shift) * p.ldx + p.x_col_off + k0 + ccol);
+            }
+        }
+    };
+    f32x4 gx[8], gy[8], nx[8], ny[8];
+    int64_t r0 = rs + 32 * wave;
+    if (r0 < re) fetch(gx, gy, r0);
+    for (; r0 < re; r0 += 128) {
+        const bool more = r0 + 128 < re;
+        if (more) fetch(nx, ny, r0 + 128);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            *reinterpret_cast<f32x4*>(sx + (4 * q + crow) * kStageStride + ccol) = gx[q];
+            *reinterpret_cast<f32x4*>(sy + (4 * q + crow) * kStageStride + ccol) = gy[q];
+        }
+        wave_fence();
+        // half-wave h takes row 2q + h of every pair
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const float* xr = sx + (2 * q + h) * kStageStride + i;
+            const float* yr = sy + (2 * q + h) * kStageStride + i;
+            const float a0 = xr[0], a1 = xr[32], b0 = yr[0], b1 = yr[32];
+            mfma2(acc[0][0], a0, b0);
+            mfma2(acc[0][1], a0, b1);
+            mfma2(acc[1][0], a1, b0);
+            mfma2(acc[1][1], a1, b1);
+            bsum0 += b0;
+            bsum1 += b1;
+        }
+        wave_fence();
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                gx[q] = nx[q];
+                gy[q] = ny[q];
+            }
+        }
+    }
+    // D[row = k][col = n]: lane holds column i, rows (reg&3) + 8*(reg>>2) + 4*h of each 32 x 32 tile
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                const int k = k0 + 32 * a + (rg & 3) + 8 * (rg >> 2) + 4 * h;
+                atomicAdd(p.dw + (int64_t)k * p.ldw + n0 + 32 * b + i, acc[a][b][rg]);
+            }
+    if (p.db && blockIdx.x == 0) {
+        bsum0 += __shfl_xor(bsum0, 32);
+        bsum1 += __shfl_xor(bsum1, 32);
+        if (h == 0) {
+            atomicAdd(p.db + n0 + i, bsum0);
+            atomicAdd(p.db + n0 + 32 + i, bsum1);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ elementwise
 
 __global__ void swish_fwd_kernel(const float* __restrict__ a, float* __restrict__ y, int64_t n) {
@@ -866,6 +958,21 @@ hipError_t t_gemm(const GemmArgs& a, bool nt, hipStream_t st) {
 hipError_t t_gemm_tn(GemmTnArgs a, hipStream_t st) {
     if (a.m == 0) return hipSuccess;
     if (a.n % 32 != 0) return hipErrorInvalidValue;
+    const bool aligned = a.ldx % 4 == 0 && a.ldy % 4 == 0 && a.x_col_off % 4 == 0 && a.dy_col_off % 4 == 0 &&
+                         (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.dy) & 15) == 0;
+    if (a.m >= 4096 && a.k % 64 == 0 && a.n % 64 == 0 && aligned) {
+        // ~2048 wavefronts over (tiles x slabs x 4), every wavefront with at least 128 rows of its own
+        const int64_t tiles64 = (int64_t)(a.k / 64) * (a.n / 64);
+        int64_t slabs = (512 + tiles64 - 1) / tiles64;
+        if (slabs > (a.m + 511) / 512) slabs = (a.m + 511) / 512;
+        if (slabs < 1) slabs = 1;
+        a.rows_per_slab = (a.m + slabs - 1) / slabs;
+        a.rows_per_slab = (a.rows_per_slab + 127) & ~(int64_t)127;   // whole 32-row chunks for all four wavefronts
+        slabs = (a.m + a.rows_per_slab - 1) / a.rows_per_slab;
+        dim3 grid((unsigned)(a.k / 64), (unsigned)(a.n / 64), (unsigned)slabs);
+        hipLaunchKernelGGL(tgemm_tn_lds_kernel, grid, dim3(256), 0, st, a);
+        return hipGetLastError();
+    }
     // enough row slabs that tiles x slabs fills the chip (~2048 wavefronts), but at least 64 rows each
     const int64_t tiles = (int64_t)((a.k + 31) / 32) * (a.n / 32);
     int64_t slabs = (2048 + tiles - 1) / tiles;
