@@ -266,7 +266,8 @@ GemmArgs ga(const float* x, int64_t ldx, const float* w, int64_t ldw, const floa
     GemmArgs a;
     a.x = x; a.ldx = ldx; a.w = w; a.ldw = ldw; a.bias = bias; a.out = out; a.ldo = ldo; a.col_off = col_off;
     a.m = m; a.k = k; a.cols = cols; a.shift = shift; a.wlen = wlen; a.accumulate = acc;
-    a.taps = 1; a.tap_stride = 0; a.tap_dir = 1;
+    a.taps = 1; a.tap_stride = 0; a.tap_dir = 1; a.x_tap_stride = 0;
+    a.residual = nullptr; a.ldr = 0; a.act_out = nullptr; a.lda = 0;
     return a;
 }
 GemmTnArgs gt(const float* x, int64_t ldx, int xoff, const float* dy, int64_t ldy, int dyoff, float* dw, int64_t ldw, float* db,
@@ -278,9 +279,10 @@ GemmTnArgs gt(const float* x, int64_t ldx, int xoff, const float* dy, int64_t ld
 }
 
 // conv1d 'same': out = sum_t shift_{t-1}(x) * K[t] + b, all taps in one product (K is [taps][64][64])
-int conv_fwd(const Ctx& c, const float* x, int kid, int bid, int taps, float* out, int64_t R, int wlen) {
+int conv_fwd(const Ctx& c, const float* x, int kid, int bid, int taps, float* out, int64_t R, int wlen, float* swish_out = nullptr) {
     GemmArgs a = ga(x, 64, c.w(kid), 64, c.w(bid), out, 64, 0, R, 64, 64, 0, wlen, 0);
     a.taps = taps; a.tap_stride = 64 * 64; a.tap_dir = 1;
+    a.act_out = swish_out; a.lda = 64;
     T_TRY(t_gemm(a, false, c.st));
     return DPTM_OK;
 }
@@ -311,12 +313,10 @@ int branch_fwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
     T_TRY(t_embed_fwd(tok, c.w(p.emb), c.w(p.pos), a.x0, R, wl, c.st));
     T_TRY(t_dropout(a.x0, R, 64, 64, wl, seed, b * 8 + 0, rt.embed, c.st));
     if ((rc = conv_fwd(c, a.x0, p.sck, p.scb, 1, a.s, R, wl))) return rc;
-    if ((rc = conv_fwd(c, a.x0, p.c3ak, p.c3ab, 3, a.a1, R, wl))) return rc;
-    T_TRY(t_swish_fwd(a.a1, a.y1, R64, c.st));
+    if ((rc = conv_fwd(c, a.x0, p.c3ak, p.c3ab, 3, a.a1, R, wl, a.y1))) return rc;       // y1 = swish(a1) in the epilogue
     if ((rc = bn_train_fwd(c, a.y1, a.z1, 64, 0, R, 64, p.bn1, a.mi1))) return rc;
     T_TRY(t_dropout(a.z1, R, 64, 64, wl, seed, b * 8 + 1, rt.conv, c.st));
-    if ((rc = conv_fwd(c, a.z1, p.c3bk, p.c3bb, 3, a.a2, R, wl))) return rc;
-    T_TRY(t_swish_fwd(a.a2, a.y2, R64, c.st));
+    if ((rc = conv_fwd(c, a.z1, p.c3bk, p.c3bb, 3, a.a2, R, wl, a.y2))) return rc;
     if ((rc = bn_train_fwd(c, a.y2, a.x1, 64, 0, R, 64, p.bn2, a.mi2))) return rc;
     T_TRY(t_add(a.x1, a.s, R64, c.st));
     for (int i = 0; i < 2; ++i) {
@@ -330,8 +330,11 @@ int branch_fwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
         T_TRY(t_gemm(ga(q.o, 64, c.w(w.wo), 64, c.w(w.bo), q.ao, 64, 0, R, 64, 64), false, c.st));
         T_TRY(t_dropout(q.ao, R, 64, 64, 0, seed, b * 8 + 2 + 2 * i, rt.tb, c.st));
         T_TRY(t_ln_fwd(q.x, q.ao, c.w(w.ln1g), c.w(w.ln1b), q.h, q.xh1, q.inv1, R, c.st));
-        T_TRY(t_gemm(ga(q.h, 64, c.w(w.f1k), 256, c.w(w.f1b), q.f1, 256, 0, R, 64, 256), false, c.st));
-        T_TRY(t_swish_fwd(q.f1, q.u, R * 256, c.st));
+        {
+            GemmArgs g1 = ga(q.h, 64, c.w(w.f1k), 256, c.w(w.f1b), q.f1, 256, 0, R, 64, 256);
+            g1.act_out = q.u; g1.lda = 256;                                                   // u = swish(f1) in the epilogue
+            T_TRY(t_gemm(g1, false, c.st));
+        }
         T_TRY(t_gemm(ga(q.u, 256, c.w(w.f2k), 64, c.w(w.f2b), q.f2, 64, 0, R, 256, 64), false, c.st));
         T_TRY(t_dropout(q.f2, R, 64, 64, 0, seed, b * 8 + 3 + 2 * i, rt.tb, c.st));
         T_TRY(t_ln_fwd(q.h, q.f2, c.w(w.ln2g), c.w(w.ln2b), xout, q.xh2, q.inv2, R, c.st));
@@ -359,18 +362,19 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
         // LayerNorm 2: dsum = d(h + f2)
         T_TRY(t_ln_bwd(dx, q.xh2, q.inv2, c.w(w.ln2g), dsum, c.g(w.ln2g), c.g(w.ln2b), R, c.st));
         // f2 branch: dropout, ffn2, swish, ffn1
-        T_TRY(hipMemcpyAsync(tmp, dsum, R64 * sizeof(float), hipMemcpyDeviceToDevice, c.st));
-        T_TRY(t_dropout(tmp, R, 64, 64, 0, seed, b * 8 + 3 + 2 * i, rt.tb, c.st));
+        T_TRY(t_dropout(tmp, R, 64, 64, 0, seed, b * 8 + 3 + 2 * i, rt.tb, c.st, dsum));
         T_TRY(t_gemm_tn(gt(q.u, 256, 0, tmp, 64, 0, c.g(w.f2k), 64, c.g(w.f2b), R, 256, 64), c.st));
         T_TRY(t_gemm(ga(tmp, 64, c.w(w.f2k), 64, nullptr, c.s->g256, 256, 0, R, 64, 256), true, c.st));       // dU
         T_TRY(t_swish_bwd(q.f1, c.s->g256, c.s->g256, R * 256, c.st));                                           // dF1
         T_TRY(t_gemm_tn(gt(q.h, 64, 0, c.s->g256, 256, 0, c.g(w.f1k), 256, c.g(w.f1b), R, 64, 256), c.st));
-        T_TRY(hipMemcpyAsync(dh, dsum, R64 * sizeof(float), hipMemcpyDeviceToDevice, c.st));                 // dH = dsum + ...
-        T_TRY(t_gemm(ga(c.s->g256, 256, c.w(w.f1k), 256, nullptr, dh, 64, 0, R, 256, 64, 0, 0, 1), true, c.st));
+        {
+            GemmArgs gh = ga(c.s->g256, 256, c.w(w.f1k), 256, nullptr, dh, 64, 0, R, 256, 64);      // dH = dsum + dF1 W1^T
+            gh.residual = dsum; gh.ldr = 64;
+            T_TRY(t_gemm(gh, true, c.st));
+        }
         // LayerNorm 1: dsum = d(x + ao)
         T_TRY(t_ln_bwd(dh, q.xh1, q.inv1, c.w(w.ln1g), dsum, c.g(w.ln1g), c.g(w.ln1b), R, c.st));
-        T_TRY(hipMemcpyAsync(tmp, dsum, R64 * sizeof(float), hipMemcpyDeviceToDevice, c.st));
-        T_TRY(t_dropout(tmp, R, 64, 64, 0, seed, b * 8 + 2 + 2 * i, rt.tb, c.st));                           // dAO
+        T_TRY(t_dropout(tmp, R, 64, 64, 0, seed, b * 8 + 2 + 2 * i, rt.tb, c.st, dsum));                     // dAO
         T_TRY(t_gemm_tn(gt(q.o, 64, 0, tmp, 64, 0, c.g(w.wo), 64, c.g(w.bo), R, 64, 64), c.st));
         T_TRY(t_gemm(ga(tmp, 64, c.w(w.wo), 64, nullptr, dh, 64, 0, R, 64, 64), true, c.st));                // dO (in dh)
         T_TRY(t_attn_bwd(q.q, q.k, q.v, q.prob, dh, c.s->gq, c.s->gk, c.s->gv, B, wl, c.st));
@@ -378,10 +382,22 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
         T_TRY(t_gemm_tn(gt(q.x, 64, 0, c.s->gk, 64, 0, c.g(w.wk), 64, c.g(w.bk), R, 64, 64), c.st));
         T_TRY(t_gemm_tn(gt(q.x, 64, 0, c.s->gv, 64, 0, c.g(w.wv), 64, c.g(w.bv), R, 64, 64), c.st));
         // dX = dsum + dQ Wq^T + dK Wk^T + dV Wv^T   (written into dx)
-        T_TRY(hipMemcpyAsync(dx, dsum, R64 * sizeof(float), hipMemcpyDeviceToDevice, c.st));
-        T_TRY(t_gemm(ga(c.s->gq, 64, c.w(w.wq), 64, nullptr, dx, 64, 0, R, 64, 64, 0, 0, 1), true, c.st));
-        T_TRY(t_gemm(ga(c.s->gk, 64, c.w(w.wk), 64, nullptr, dx, 64, 0, R, 64, 64, 0, 0, 1), true, c.st));
-        T_TRY(t_gemm(ga(c.s->gv, 64, c.w(w.wv), 64, nullptr, dx, 64, 0, R, 64, 64, 0, 0, 1), true, c.st));
+        {
+            // one pass when the three gradient arrays and the three kernels are evenly spaced in their buffers
+            const int64_t xs = c.s->gk - c.s->gq, ws = c.w(w.wk) - c.w(w.wq);
+            if (c.s->gv - c.s->gk == xs && c.w(w.wv) - c.w(w.wk) == ws && xs > 0 && ws > 0) {
+                GemmArgs gx3 = ga(c.s->gq, 64, c.w(w.wq), 64, nullptr, dx, 64, 0, R, 64, 64);
+                gx3.taps = 3; gx3.tap_dir = 0; gx3.tap_stride = ws; gx3.x_tap_stride = xs;
+                gx3.residual = dsum; gx3.ldr = 64;
+                T_TRY(t_gemm(gx3, true, c.st));
+            } else {
+                GemmArgs gq = ga(c.s->gq, 64, c.w(w.wq), 64, nullptr, dx, 64, 0, R, 64, 64);
+                gq.residual = dsum; gq.ldr = 64;
+                T_TRY(t_gemm(gq, true, c.st));
+                T_TRY(t_gemm(ga(c.s->gk, 64, c.w(w.wk), 64, nullptr, dx, 64, 0, R, 64, 64, 0, 0, 1), true, c.st));
+                T_TRY(t_gemm(ga(c.s->gv, 64, c.w(w.wv), 64, nullptr, dx, 64, 0, R, 64, 64, 0, 0, 1), true, c.st));
+            }
+        }
     }
     // conv block: x1 = BN2(swish(conv3b(z1))) + conv1(x0); dx = d(x1)
     // BatchNorm 2 -> dY2 (tmp) -> dA2 (tmp)

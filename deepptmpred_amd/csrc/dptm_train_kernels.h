@@ -25,6 +25,11 @@ struct GemmArgs {
                          // row shift tap_dir * (t - taps/2); `shift` is ignored then
     int64_t tap_stride;
     int tap_dir;
+    int64_t x_tap_stride;    // floats added to x per tap (taps with tap_dir 0: a sum of products over separate operands)
+    const float* residual;   // optional [m][ldr]: added to the result (the same columns as out, without col_off)
+    int64_t ldr;
+    float* act_out;          // optional [m][lda]: swish(result) is stored here as well
+    int64_t lda;
 };
 
 struct GemmTnArgs {
@@ -57,8 +62,9 @@ hipError_t t_copy_cols(float* dst, int64_t ldd, int dc, const float* src, int64_
 // batch size and positive count of the loss weights.  t_set_step writes them (stream-ordered).
 enum StepParam { kStepSeed = 0, kStepNGlobal = 1, kStepNPosGlobal = 2, kStepParams = 4 };
 hipError_t t_set_step(unsigned* step_params, unsigned seed, float n_global, float n_pos_global, hipStream_t st);
+// x = dropout(src ? src : x); with rate 0 and a src this is a plain copy
 hipError_t t_dropout(float* x, int64_t rows, int cols, int64_t ld, int wlen_spatial, const unsigned* step_params, unsigned stream,
-                     float rate, hipStream_t st);
+                     float rate, hipStream_t st, const float* src = nullptr);
 hipError_t t_embed_fwd(const uint8_t* tok, const float* E, const float* P, float* x, int64_t rows, int wlen, hipStream_t st);
 hipError_t t_embed_bwd(const uint8_t* tok, const float* dx, float* dE, float* dP, int64_t rows, int wlen, hipStream_t st);
 hipError_t t_colsum2(const float* x, const float* y, int64_t rows, int cols, float* stats, hipStream_t st);

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void tgemm_kernel(GemmArgs p) {
         const int shift = p.taps > 1 ? p.tap_dir * (tp - p.taps / 2) : p.shift;
         const float* wm = p.w + tp * p.tap_stride;
         const bool ok = row_ok(r, shift, p.m, p.wlen);
-        const float* xin = p.x + (ok ? (r + shift) : 0) * p.ldx + 4 * h;
+        const float* xin = p.x + tp * p.x_tap_stride + (ok ? (r + shift) : 0) * p.ldx + 4 * h;
         // the contraction is walked in blocks of 64 inputs whose operands are all requested before the first
         // MFMA of the block: these layers are a few steps deep, so the loads' latency is the cost to hide
         for (int ub = 0; ub < k8; ub += 8) {
@@ -108,8 +108,16 @@ __global__ __launch_bounds__(256) void tgemm_kernel(GemmArgs p) {
         for (int g = 0; g < 4; ++g) {
             f32x4 v = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
             f32x4* dst = reinterpret_cast<f32x4*>(orow + 32 * t + 8 * g);
+            const int cc = c0 + 4 * h + 32 * t + 8 * g;
+            if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + r * p.ldr + cc);
             if (p.accumulate) v += *dst;
             *dst = v;
+            if (p.act_out) {
+                f32x4 sw;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sw[e] = v[e] * sigmoidf_(v[e]);
+                *reinterpret_cast<f32x4*>(p.act_out + r * p.lda + cc) = sw;
+            }
         }
 }
 
@@ -172,7 +180,8 @@ __global__ __launch_bounds__(512) void tgemm_lds_kernel(GemmArgs p) {
         for (int i = 0; i < 8; ++i) {
             const int64_t rr = r0 + 4 * i + crow + shift;
             g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (rr >= 0 && rr < p.m) g[i] = *reinterpret_cast<const f32x4*>(p.x + rr * p.ldx + 64 * kb + ccol);
+            if (rr >= 0 && rr < p.m)
+                g[i] = *reinterpret_cast<const f32x4*>(p.x + tp * p.x_tap_stride + rr * p.ldx + 64 * kb + ccol);
         }
     };
     for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntile; tile += (int64_t)gridDim.x * 8) {
@@ -233,8 +242,15 @@ __global__ __launch_bounds__(512) void tgemm_lds_kernel(GemmArgs p) {
             if (rr < p.m) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(stage + (4 * i + crow) * kStageStride + ccol);
                 f32x4* dst = reinterpret_cast<f32x4*>(p.out + rr * p.ldo + p.col_off + c0 + ccol);
+                if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + rr * p.ldr + c0 + ccol);
                 if (p.accumulate) v += *dst;
                 *dst = v;
+                if (p.act_out) {
+                    f32x4 sw;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sw[e] = v[e] * sigmoidf_(v[e]);
+                    *reinterpret_cast<f32x4*>(p.act_out + rr * p.lda + c0 + ccol) = sw;
+                }
             }
         }
         wave_fence();
@@ -415,16 +431,17 @@ __global__ void copy_cols_kernel(float* __restrict__ dst, int64_t ldd, int dc, c
 
 // inverted dropout in place.  spatial: one mask value per (sample, channel) of a
 // [samples][wlen][cols] stack; otherwise per element.  ld = row stride, cols = row width.
-__global__ void dropout_kernel(float* __restrict__ x, int64_t rows, int cols, int64_t ld, int wlen_spatial,
-                               const unsigned* __restrict__ step_params, unsigned stream, unsigned thr, float scale) {
+__global__ void dropout_kernel(float* __restrict__ x, const float* __restrict__ src, int64_t rows, int cols, int64_t ld,
+                               int wlen_spatial, const unsigned* __restrict__ step_params, unsigned stream, unsigned thr,
+                               float scale) {
     const unsigned seed = step_params[kStepSeed];
     const int64_t total = rows * cols;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / cols;
         const int c = (int)(i - r * cols);
         const unsigned idx = wlen_spatial ? (unsigned)((r / wlen_spatial) * cols + c) : (unsigned)i;
-        float* d = x + r * ld + c;
-        *d = hash_u32(seed, stream, idx) >= thr ? *d * scale : 0.f;
+        const float v = src[r * ld + c];
+        x[r * ld + c] = hash_u32(seed, stream, idx) >= thr ? v * scale : 0.f;
     }
 }
 
@@ -922,8 +939,10 @@ hipError_t t_gemm(const GemmArgs& a, bool nt, hipStream_t st) {
     if (a.cols % 64 != 0 || a.k % 8 != 0) return hipErrorInvalidValue;
     const int ntaps = a.taps > 1 ? a.taps : 1;
     // large row stacks whose weight tile fits LDS take the staged kernel; operands must allow 16-byte accesses
-    const bool aligned = a.ldx % 4 == 0 && a.ldo % 4 == 0 && a.col_off % 4 == 0 &&
-                         (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
+    const bool aligned = a.ldx % 4 == 0 && a.ldo % 4 == 0 && a.col_off % 4 == 0 && a.x_tap_stride % 4 == 0 &&
+                         (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
+                         (!a.residual || (a.ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(a.residual) & 15) == 0)) &&
+                         (!a.act_out || (a.lda % 4 == 0 && (reinterpret_cast<uintptr_t>(a.act_out) & 15) == 0));
     if (a.m >= 4096 && a.k % 64 == 0 && ntaps * a.k <= 320 && aligned) {
         const size_t lds = (size_t)ntaps * a.k * 256 + (size_t)8 * 32 * kStageStride * sizeof(float);
         static bool attr_done[64][2] = {};
@@ -1004,12 +1023,17 @@ hipError_t t_copy_cols(float* dst, int64_t ldd, int dc, const float* src, int64_
     return hipGetLastError();
 }
 hipError_t t_dropout(float* x, int64_t rows, int cols, int64_t ld, int wlen_spatial, const unsigned* step_params, unsigned stream,
-                     float rate, hipStream_t st) {
-    if (rate <= 0.f || rows == 0) return hipSuccess;
+                     float rate, hipStream_t st, const float* src) {
+    if (rows == 0) return hipSuccess;
+    if (rate <= 0.f) {
+        if (!src || src == x) return hipSuccess;
+        if (ld == cols) return hipMemcpyAsync(x, src, (size_t)rows * cols * sizeof(float), hipMemcpyDeviceToDevice, st);
+        return hipMemcpy2DAsync(x, ld * sizeof(float), src, ld * sizeof(float), cols * sizeof(float), rows, hipMemcpyDeviceToDevice, st);
+    }
     double t = (double)rate * 4294967296.0;
     const unsigned thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
-    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, st, x, rows, cols, ld, wlen_spatial, step_params,
-                       stream, thr, 1.0f / (1.0f - rate));
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, st, x, src ? src : x, rows, cols, ld, wlen_spatial,
+                       step_params, stream, thr, 1.0f / (1.0f - rate));
     return hipGetLastError();
 }
 hipError_t t_embed_fwd(const uint8_t* tok, const float* E, const float* P, float* x, int64_t rows, int wlen, hipStream_t st) {
