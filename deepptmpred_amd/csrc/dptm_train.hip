@@ -43,7 +43,7 @@ struct Tn {          // one tensor of the canonical order
     bool l2;
 };
 
-struct BnP { int gamma, beta, mean, var; };
+struct BnP { int gamma, beta, mean, var, slot; };   // slot: index of the layer's column-sum buffers
 struct TbP { int wq, bq, wk, bk, wv, bv, wo, bo, f1k, f1b, f2k, f2b, ln1g, ln1b, ln2g, ln2b; };
 struct BranchP { int emb, pos, sck, scb, c3ak, c3ab; BnP bn1; int c3bk, c3bb; BnP bn2; TbP tb[2]; int poolk, poolb; };
 struct DenseP { int k, b; BnP bn; };
@@ -60,7 +60,8 @@ struct PMap {
         canon_total += size;
         return (int)t.size() - 1;
     }
-    BnP add_bn(int n) { BnP b; b.gamma = add(n); b.beta = add(n); b.mean = add(n, false); b.var = add(n, false); return b; }
+    int n_bn = 0;
+    BnP add_bn(int n) { BnP b; b.gamma = add(n); b.beta = add(n); b.mean = add(n, false); b.var = add(n, false); b.slot = n_bn++; return b; }
     void build() {
         const int W[3] = {21, 33, 51};
         for (int b = 0; b < 3; ++b) {
@@ -122,11 +123,13 @@ struct dptm_trainer {
     // per-site tensors
     float *sa, *sy, *smi, *ea, *ey, *emi, *e1, *e2a, *concat, *t1a, *t1y, *t1mi, *t1z, *t2a, *t2y, *t2mi, *t2z, *proba;
     float* d_loss = nullptr;
+    // column sums of every BatchNorm, forward [slot] and backward [kBnLayers + slot], 1024 floats each: zeroed once per step
+    float* bn_slots = nullptr;
     // Scratch of one concurrent lane of the step: the three sequence branches run on side streams next to
     // the per-site layers, so each owns its gradient scratch ([rows][64] / [rows][256]) and BatchNorm sums.
     struct Scratch {
         float *g64a = nullptr, *g64b = nullptr, *g64c = nullptr, *g64d = nullptr, *g256 = nullptr;
-        float *gq = nullptr, *gk = nullptr, *gv = nullptr, *bnstat = nullptr, *bnsums = nullptr, *bnsums_all = nullptr;
+        float *gq = nullptr, *gk = nullptr, *gv = nullptr, *bnsums_all = nullptr;
     };
     Scratch sc[4];                        // [0..2] sequence branches, [3] per-site layers (BatchNorm sums only)
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
@@ -161,6 +164,7 @@ struct dptm_trainer {
 namespace {
 
 const int kW[3] = {21, 33, 51};
+constexpr int kBnLayers = 10;   // 2 per sequence branch + struct, ESM, two trunk layers
 
 int alloc_acts(dptm_trainer* t) {
     const int64_t B = t->max_batch;
@@ -186,10 +190,10 @@ int alloc_acts(dptm_trainer* t) {
           need(t->emi, 1024) && need(t->e1, B * 512) && need(t->e2a, B * 256) && need(t->concat, B * 576) &&
           need(t->t1a, B * 512) && need(t->t1y, B * 512) && need(t->t1mi, 1024) && need(t->t1z, B * 512) &&
           need(t->t2a, B * 256) && need(t->t2y, B * 256) && need(t->t2mi, 512) && need(t->t2z, B * 256) &&
-          need(t->proba, B * 2) && need(t->d_loss, 64);
+          need(t->proba, B * 2) && need(t->d_loss, 64) && need(t->bn_slots, 2 * kBnLayers * 1024);
     for (int b = 0; b < 4; ++b) {
         dptm_trainer::Scratch& s = t->sc[b];
-        ok &= need(s.bnstat, 1024) && need(s.bnsums, 1024) && need(s.bnsums_all, 1024);
+        ok &= need(s.bnsums_all, 1024);
         if (b == 3) break;
         const size_t RM = (size_t)B * kW[b];
         ok &= need(s.g64a, RM * 64) && need(s.g64b, RM * 64) && need(s.g64c, RM * 64) && need(s.g64d, RM * 64) &&
@@ -207,7 +211,7 @@ size_t arena_bytes(int64_t B) {
         f += R * 64 * 9 + 2 * (R * 64 * 10 + R * 256 * 2 + R * 2 + (size_t)B * 4 * kW[b] * kW[b]) + R * 64 + R * 2;
     }
     f += (size_t)B * (128 * 2 + 512 * 3 + 256 + 576 + 512 * 3 + 256 * 3 + 2);
-    f += (size_t)B * (21 + 33 + 51) * (64 * 7 + 256) + 12 * 1024 + (size_t)B * (576 + 1024 + 512 + 128);
+    f += (size_t)B * (21 + 33 + 51) * (64 * 7 + 256) + (4 + 2 * 10) * 1024 + (size_t)B * (576 + 1024 + 512 + 128);
     return f * sizeof(float) + (size_t)640 * 256 + (1 << 20);   // + per-allocation rounding slack
 }
 
@@ -233,13 +237,13 @@ int replica_sum(const Ctx& c, float* buf, int64_t count) {
 
 // BatchNorm in training mode on y [rows][cols] -> z (may live inside a wider buffer)
 int bn_train_fwd(const Ctx& c, const float* y, float* z, int64_t ldz, int zoff, int64_t rows, int cols, const BnP& bn, float* mi) {
-    T_TRY(hipMemsetAsync(c.s->bnstat, 0, 2 * cols * sizeof(float), c.st));
-    T_TRY(t_colsum2(y, nullptr, rows, cols, c.s->bnstat, c.st));
-    int rc = replica_sum(c, c.s->bnstat, 2 * cols);
+    float* stats = c.t->bn_slots + (size_t)bn.slot * 1024;
+    T_TRY(t_colsum2(y, nullptr, rows, cols, stats, c.st));
+    int rc = replica_sum(c, stats, 2 * cols);
     if (rc) return rc;
     // the batch statistics ride in the (otherwise unused) moving-stat slots of the gradient buffer
-    T_TRY(t_bn_finalize(c.s->bnstat, cols, global_rows(c.t, rows), mi, c.g(bn.mean), c.g(bn.var), c.st));
-    T_TRY(t_bn_fwd(y, z, rows, cols, mi, c.w(bn.gamma), c.w(bn.beta), ldz, zoff, c.st));
+    T_TRY(t_bn_fwd(y, z, rows, cols, stats, global_rows(c.t, rows), mi, c.g(bn.mean), c.g(bn.var), c.w(bn.gamma), c.w(bn.beta), ldz,
+                   zoff, c.st));
     return DPTM_OK;
 }
 
@@ -248,15 +252,16 @@ int bn_train_fwd(const Ctx& c, const float* y, float* z, int64_t ldz, int zoff, 
 // (the gradient all-reduce adds the shares up).
 int bn_train_bwd(const Ctx& c, const float* dz, int64_t lddz, int dzoff, const float* y, float* dy, int64_t rows, int cols,
                  const float* mi, const BnP& bn) {
-    T_TRY(t_bn_bwd_reduce(dz, lddz, dzoff, y, rows, cols, mi, c.s->bnsums, c.st));
-    const float* all = c.s->bnsums;
+    float* sums = c.t->bn_slots + (size_t)(kBnLayers + bn.slot) * 1024;
+    T_TRY(t_bn_bwd_reduce(dz, lddz, dzoff, y, rows, cols, mi, sums, c.st));
+    const float* all = sums;
     if (c.t->ar_fn) {
-        T_TRY(hipMemcpyAsync(c.s->bnsums_all, c.s->bnsums, 2 * cols * sizeof(float), hipMemcpyDeviceToDevice, c.st));
+        T_TRY(hipMemcpyAsync(c.s->bnsums_all, sums, 2 * cols * sizeof(float), hipMemcpyDeviceToDevice, c.st));
         int rc = replica_sum(c, c.s->bnsums_all, 2 * cols);
         if (rc) return rc;
         all = c.s->bnsums_all;
     }
-    T_TRY(t_bn_bwd_apply(dz, lddz, dzoff, y, dy, rows, cols, mi, c.w(bn.gamma), all, global_rows(c.t, rows), c.s->bnsums,
+    T_TRY(t_bn_bwd_apply(dz, lddz, dzoff, y, dy, rows, cols, mi, c.w(bn.gamma), all, global_rows(c.t, rows), sums,
                          c.g(bn.gamma), c.g(bn.beta), c.st));
     return DPTM_OK;
 }
@@ -268,6 +273,7 @@ GemmArgs ga(const float* x, int64_t ldx, const float* w, int64_t ldw, const floa
     a.m = m; a.k = k; a.cols = cols; a.shift = shift; a.wlen = wlen; a.accumulate = acc;
     a.taps = 1; a.tap_stride = 0; a.tap_dir = 1; a.x_tap_stride = 0;
     a.residual = nullptr; a.ldr = 0; a.act_out = nullptr; a.lda = 0;
+    a.batch = 1; a.bx = a.bw = a.bb = a.bo = 0;
     return a;
 }
 GemmTnArgs gt(const float* x, int64_t ldx, int xoff, const float* dy, int64_t ldy, int dyoff, float* dw, int64_t ldw, float* db,
@@ -275,6 +281,7 @@ GemmTnArgs gt(const float* x, int64_t ldx, int xoff, const float* dy, int64_t ld
     GemmTnArgs a;
     a.x = x; a.ldx = ldx; a.x_col_off = xoff; a.dy = dy; a.ldy = ldy; a.dy_col_off = dyoff; a.dw = dw; a.ldw = ldw; a.db = db;
     a.m = m; a.k = k; a.n = n; a.shift = shift; a.wlen = wlen; a.rows_per_slab = 0;
+    a.slabs = 1; a.batch = 1; a.bx = a.bdy = a.bdw = a.bdb = 0;
     return a;
 }
 
@@ -323,9 +330,19 @@ int branch_fwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
         TbAct& q = a.tb[i];
         const TbP& w = p.tb[i];
         float* xout = i == 0 ? a.tb[1].x : a.xout;
-        T_TRY(t_gemm(ga(q.x, 64, c.w(w.wq), 64, c.w(w.bq), q.q, 64, 0, R, 64, 64), false, c.st));
-        T_TRY(t_gemm(ga(q.x, 64, c.w(w.wk), 64, c.w(w.bk), q.k, 64, 0, R, 64, 64), false, c.st));
-        T_TRY(t_gemm(ga(q.x, 64, c.w(w.wv), 64, c.w(w.bv), q.v, 64, 0, R, 64, 64), false, c.st));
+        {
+            // Q, K, V: three products of the same rows, one launch when kernels, biases and outputs are evenly spaced
+            const int64_t ws = c.w(w.wk) - c.w(w.wq), bs = c.w(w.bk) - c.w(w.bq), os = q.k - q.q;
+            if (c.w(w.wv) - c.w(w.wk) == ws && c.w(w.bv) - c.w(w.bk) == bs && q.v - q.k == os) {
+                GemmArgs g3 = ga(q.x, 64, c.w(w.wq), 64, c.w(w.bq), q.q, 64, 0, R, 64, 64);
+                g3.batch = 3; g3.bx = 0; g3.bw = ws; g3.bb = bs; g3.bo = os;
+                T_TRY(t_gemm(g3, false, c.st));
+            } else {
+                T_TRY(t_gemm(ga(q.x, 64, c.w(w.wq), 64, c.w(w.bq), q.q, 64, 0, R, 64, 64), false, c.st));
+                T_TRY(t_gemm(ga(q.x, 64, c.w(w.wk), 64, c.w(w.bk), q.k, 64, 0, R, 64, 64), false, c.st));
+                T_TRY(t_gemm(ga(q.x, 64, c.w(w.wv), 64, c.w(w.bv), q.v, 64, 0, R, 64, 64), false, c.st));
+            }
+        }
         T_TRY(t_attn_fwd(q.q, q.k, q.v, q.o, q.prob, B, wl, c.st));
         T_TRY(t_gemm(ga(q.o, 64, c.w(w.wo), 64, c.w(w.bo), q.ao, 64, 0, R, 64, 64), false, c.st));
         T_TRY(t_dropout(q.ao, R, 64, 64, 0, seed, b * 8 + 2 + 2 * i, rt.tb, c.st));
@@ -378,9 +395,18 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
         T_TRY(t_gemm_tn(gt(q.o, 64, 0, tmp, 64, 0, c.g(w.wo), 64, c.g(w.bo), R, 64, 64), c.st));
         T_TRY(t_gemm(ga(tmp, 64, c.w(w.wo), 64, nullptr, dh, 64, 0, R, 64, 64), true, c.st));                // dO (in dh)
         T_TRY(t_attn_bwd(q.q, q.k, q.v, q.prob, dh, c.s->gq, c.s->gk, c.s->gv, B, wl, c.st));
-        T_TRY(t_gemm_tn(gt(q.x, 64, 0, c.s->gq, 64, 0, c.g(w.wq), 64, c.g(w.bq), R, 64, 64), c.st));
-        T_TRY(t_gemm_tn(gt(q.x, 64, 0, c.s->gk, 64, 0, c.g(w.wk), 64, c.g(w.bk), R, 64, 64), c.st));
-        T_TRY(t_gemm_tn(gt(q.x, 64, 0, c.s->gv, 64, 0, c.g(w.wv), 64, c.g(w.bv), R, 64, 64), c.st));
+        {
+            const int64_t ys = c.s->gk - c.s->gq, ws = c.g(w.wk) - c.g(w.wq), bs = c.g(w.bk) - c.g(w.bq);
+            if (c.s->gv - c.s->gk == ys && c.g(w.wv) - c.g(w.wk) == ws && c.g(w.bv) - c.g(w.bk) == bs) {
+                GemmTnArgs g3 = gt(q.x, 64, 0, c.s->gq, 64, 0, c.g(w.wq), 64, c.g(w.bq), R, 64, 64);
+                g3.batch = 3; g3.bx = 0; g3.bdy = ys; g3.bdw = ws; g3.bdb = bs;
+                T_TRY(t_gemm_tn(g3, c.st));
+            } else {
+                T_TRY(t_gemm_tn(gt(q.x, 64, 0, c.s->gq, 64, 0, c.g(w.wq), 64, c.g(w.bq), R, 64, 64), c.st));
+                T_TRY(t_gemm_tn(gt(q.x, 64, 0, c.s->gk, 64, 0, c.g(w.wk), 64, c.g(w.bk), R, 64, 64), c.st));
+                T_TRY(t_gemm_tn(gt(q.x, 64, 0, c.s->gv, 64, 0, c.g(w.wv), 64, c.g(w.bv), R, 64, 64), c.st));
+            }
+        }
         // dX = dsum + dQ Wq^T + dK Wk^T + dV Wv^T   (written into dx)
         {
             // one pass when the three gradient arrays and the three kernels are evenly spaced in their buffers
@@ -538,6 +564,7 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
     int rc;
     T_TRY(hipMemsetAsync(t->G, 0, (size_t)pm.total * sizeof(float), st));
     T_TRY(hipMemsetAsync(t->d_loss, 0, 64 * sizeof(float), st));
+    T_TRY(hipMemsetAsync(t->bn_slots, 0, (size_t)2 * kBnLayers * 1024 * sizeof(float), st));
     // ---------------- forward: the three sequence branches on side streams, the per-site layers on `st`
     T_TRY(hipEventRecord(t->ev_fork[0], st));
     for (int b = 0; b < 3; ++b) {

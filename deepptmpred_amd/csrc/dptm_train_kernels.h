@@ -30,6 +30,8 @@ struct GemmArgs {
     int64_t ldr;
     float* act_out;          // optional [m][lda]: swish(result) is stored here as well
     int64_t lda;
+    int batch;               // > 1: that many independent products in one launch (grid.z); operand b of product z is
+    int64_t bx, bw, bb, bo;  // x + z*bx, w + z*bw, bias + z*bb, out + z*bo
 };
 
 struct GemmTnArgs {
@@ -48,6 +50,9 @@ struct GemmTnArgs {
     int shift;
     int wlen;
     int64_t rows_per_slab;   // set by the launcher
+    int slabs;               // set by the launcher
+    int batch;               // > 1: independent products in one launch: x + z*bx, dy + z*bdy, dw + z*bdw, db + z*bdb
+    int64_t bx, bdy, bdw, bdb;
 };
 
 hipError_t t_gemm(const GemmArgs& a, bool nt, hipStream_t st);
@@ -68,10 +73,11 @@ hipError_t t_dropout(float* x, int64_t rows, int cols, int64_t ld, int wlen_spat
 hipError_t t_embed_fwd(const uint8_t* tok, const float* E, const float* P, float* x, int64_t rows, int wlen, hipStream_t st);
 hipError_t t_embed_bwd(const uint8_t* tok, const float* dx, float* dE, float* dP, int64_t rows, int wlen, hipStream_t st);
 hipError_t t_colsum2(const float* x, const float* y, int64_t rows, int cols, float* stats, hipStream_t st);
-hipError_t t_bn_finalize(const float* stats, int cols, int64_t rows, float* mean_inv, float* batch_mean,
-                         float* batch_var, hipStream_t st);
-hipError_t t_bn_fwd(const float* y, float* z, int64_t rows, int cols, const float* mean_inv, const float* gamma,
-                    const float* beta, int64_t ldz, int z_col_off, hipStream_t st);
+// stats: [sum | sum of squares] of the columns of y over rows_global rows (the caller zeroes and fills it)
+hipError_t t_bn_fwd(const float* y, float* z, int64_t rows, int cols, const float* stats, int64_t rows_global, float* mean_inv,
+                    float* batch_mean, float* batch_var, const float* gamma, const float* beta, int64_t ldz, int z_col_off,
+                    hipStream_t st);
+// sums must be zero on entry
 hipError_t t_bn_bwd_reduce(const float* dz, int64_t lddz, int dz_col_off, const float* y, int64_t rows, int cols,
                            const float* mean_inv, float* sums, hipStream_t st);
 hipError_t t_bn_bwd_apply(const float* dz, int64_t lddz, int dz_col_off, const float* y, float* dy, int64_t rows, int cols,

@@ -48,6 +48,11 @@ __device__ __forceinline__ bool row_ok(int64_t r, int s, int64_t m, int wlen) {
 // ------------------------------------------------------------------------------------
 template <bool NT>
 __global__ __launch_bounds__(256) void tgemm_kernel(GemmArgs p) {
+    if (p.batch > 1) {
+        const int z = blockIdx.z;
+        p.x += z * p.bx; p.w += z * p.bw; p.out += z * p.bo;
+        if (p.bias) p.bias += z * p.bb;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, j = lane & 31;
     const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
@@ -144,6 +149,11 @@ __device__ __forceinline__ void wave_fence() {
 template <bool NT>
 __global__ __launch_bounds__(512) void tgemm_lds_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (p.batch > 1) {
+        const int z = blockIdx.z;
+        p.x += z * p.bx; p.w += z * p.bw; p.out += z * p.bo;
+        if (p.bias) p.bias += z * p.bb;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, j = lane & 31;
     const int c0 = blockIdx.y * 64;
@@ -263,9 +273,15 @@ __global__ __launch_bounds__(512) void tgemm_lds_kernel(GemmArgs p) {
 // grid = (ceil(K/32), N/32, row slabs), block 64.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void tgemm_tn_kernel(GemmTnArgs p) {
+    const int zb = p.batch > 1 ? blockIdx.z / p.slabs : 0;
+    const int zslab = blockIdx.z - zb * p.slabs;
+    if (p.batch > 1) {
+        p.x += zb * p.bx; p.dy += zb * p.bdy; p.dw += zb * p.bdw;
+        if (p.db) p.db += zb * p.bdb;
+    }
     const int lane = threadIdx.x, h = lane >> 5, i = lane & 31;
     const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
-    const int64_t rs = (int64_t)blockIdx.z * p.rows_per_slab;
+    const int64_t rs = (int64_t)zslab * p.rows_per_slab;
     const int64_t re = min(p.m, rs + p.rows_per_slab);
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
@@ -310,11 +326,17 @@ __global__ __launch_bounds__(64) void tgemm_tn_kernel(GemmTnArgs p) {
 // grid = (k/64, n/64, slabs), block 256 = 4 wavefronts that interleave the slab's chunks.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tgemm_tn_lds_kernel(GemmTnArgs p) {
+    const int zb = p.batch > 1 ? blockIdx.z / p.slabs : 0;
+    const int zslab = blockIdx.z - zb * p.slabs;
+    if (p.batch > 1) {
+        p.x += zb * p.bx; p.dy += zb * p.bdy; p.dw += zb * p.bdw;
+        if (p.db) p.db += zb * p.bdb;
+    }
     __shared__ __attribute__((aligned(16))) float stage_all[4][2][32 * kStageStride];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, i = lane & 31;
     const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
-    const int64_t rs = (int64_t)blockIdx.z * p.rows_per_slab;
+    const int64_t rs = (int64_t)zslab * p.rows_per_slab;
     const int64_t re = min(p.m, rs + p.rows_per_slab);
     float* sx = stage_all[wave][0];
     float* sy = stage_all[wave][1];
@@ -508,30 +530,32 @@ __global__ __launch_bounds__(256) void colsum2_kernel(const float* __restrict__ 
     }
 }
 
-// from the column sums: mean, inv = rsqrt(var + eps); the batch mean and (biased) variance
-// are also left in batch_mean / batch_var for the moving-statistics update
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, int cols, float inv_rows, float* __restrict__ mean_inv,
-                                   float* __restrict__ batch_mean, float* __restrict__ batch_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    const float mu = stats[c] * inv_rows;
-    float var = stats[cols + c] * inv_rows - mu * mu;
-    var = var < 0.f ? 0.f : var;
-    mean_inv[c] = mu;
-    mean_inv[cols + c] = rsqrtf(var + 1e-3f);
-    batch_mean[c] = mu;
-    batch_var[c] = var;
-}
-
-// z = (y - mean) * inv * gamma + beta
+// z = (y - mean) * inv * gamma + beta with mean / inv = rsqrt(var + eps) taken straight from the column sums
+// (stats = [sum | sum of squares] over inv_rows^-1 rows).  The first workgroup also leaves mean | inv in
+// mean_inv for the backward pass and the batch mean / (biased) variance for the moving-statistics update.
 __global__ void bn_fwd_kernel(const float* __restrict__ y, float* __restrict__ z, int64_t rows, int cols,
-                              const float* __restrict__ mean_inv, const float* __restrict__ gamma,
-                              const float* __restrict__ beta, int64_t ldz, int z_col_off) {
+                              const float* __restrict__ stats, float inv_rows, float* __restrict__ mean_inv,
+                              float* __restrict__ batch_mean, float* __restrict__ batch_var,
+                              const float* __restrict__ gamma, const float* __restrict__ beta, int64_t ldz, int z_col_off) {
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+            const float mu = stats[c] * inv_rows;
+            float var = stats[cols + c] * inv_rows - mu * mu;
+            var = var < 0.f ? 0.f : var;
+            mean_inv[c] = mu;
+            mean_inv[cols + c] = rsqrtf(var + 1e-3f);
+            batch_mean[c] = mu;
+            batch_var[c] = var;
+        }
+    }
     const int64_t total = rows * cols;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / cols;
         const int c = (int)(i - r * cols);
-        z[r * ldz + z_col_off + c] = (y[i] - mean_inv[c]) * mean_inv[cols + c] * gamma[c] + beta[c];
+        const float mu = stats[c] * inv_rows;
+        float var = stats[cols + c] * inv_rows - mu * mu;
+        var = var < 0.f ? 0.f : var;
+        z[r * ldz + z_col_off + c] = (y[i] - mu) * rsqrtf(var + 1e-3f) * gamma[c] + beta[c];
     }
 }
 
@@ -959,14 +983,14 @@ hipError_t t_gemm(const GemmArgs& a, bool nt, hipStream_t st) {
         int64_t gx = 512 / ycols;                     // about two workgroups per CU over all column tiles
         if (gx < 1) gx = 1;
         if (gx > tiles8) gx = tiles8;
-        dim3 grid((unsigned)gx, ycols);
+        dim3 grid((unsigned)gx, ycols, (unsigned)(a.batch > 1 ? a.batch : 1));
         if (nt)
             hipLaunchKernelGGL(tgemm_lds_kernel<true>, grid, dim3(512), lds, st, a);
         else
             hipLaunchKernelGGL(tgemm_lds_kernel<false>, grid, dim3(512), lds, st, a);
         return hipGetLastError();
     }
-    dim3 grid((unsigned)((a.m + 127) / 128), (unsigned)(a.cols / 64));
+    dim3 grid((unsigned)((a.m + 127) / 128), (unsigned)(a.cols / 64), (unsigned)(a.batch > 1 ? a.batch : 1));
     if (nt)
         hipLaunchKernelGGL(tgemm_kernel<true>, grid, dim3(256), 0, st, a);
     else
@@ -988,7 +1012,8 @@ hipError_t t_gemm_tn(GemmTnArgs a, hipStream_t st) {
         a.rows_per_slab = (a.m + slabs - 1) / slabs;
         a.rows_per_slab = (a.rows_per_slab + 127) & ~(int64_t)127;   // whole 32-row chunks for all four wavefronts
         slabs = (a.m + a.rows_per_slab - 1) / a.rows_per_slab;
-        dim3 grid((unsigned)(a.k / 64), (unsigned)(a.n / 64), (unsigned)slabs);
+        a.slabs = (int)slabs;
+        dim3 grid((unsigned)(a.k / 64), (unsigned)(a.n / 64), (unsigned)(slabs * (a.batch > 1 ? a.batch : 1)));
         hipLaunchKernelGGL(tgemm_tn_lds_kernel, grid, dim3(256), 0, st, a);
         return hipGetLastError();
     }
@@ -1000,7 +1025,8 @@ hipError_t t_gemm_tn(GemmTnArgs a, hipStream_t st) {
     a.rows_per_slab = (a.m + slabs - 1) / slabs;
     a.rows_per_slab = (a.rows_per_slab + 7) & ~(int64_t)7;   // multiple of 8: four row pairs per loop trip
     slabs = (a.m + a.rows_per_slab - 1) / a.rows_per_slab;
-    dim3 grid((unsigned)((a.k + 31) / 32), (unsigned)(a.n / 32), (unsigned)slabs);
+    a.slabs = (int)slabs;
+    dim3 grid((unsigned)((a.k + 31) / 32), (unsigned)(a.n / 32), (unsigned)(slabs * (a.batch > 1 ? a.batch : 1)));
     hipLaunchKernelGGL(tgemm_tn_kernel, grid, dim3(64), 0, st, a);
     return hipGetLastError();
 }
@@ -1060,21 +1086,17 @@ hipError_t t_colsum2(const float* x, const float* y, int64_t rows, int cols, flo
     hipLaunchKernelGGL(colsum2_kernel, grid, dim3(256), 0, st, x, y, rows, cols, (int64_t)cols, stats, rpb);
     return hipGetLastError();
 }
-hipError_t t_bn_finalize(const float* stats, int cols, int64_t rows, float* mean_inv, float* batch_mean,
-                         float* batch_var, hipStream_t st) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, stats, cols, 1.0f / (float)rows,
-                       mean_inv, batch_mean, batch_var);
-    return hipGetLastError();
-}
-hipError_t t_bn_fwd(const float* y, float* z, int64_t rows, int cols, const float* mean_inv, const float* gamma,
-                    const float* beta, int64_t ldz, int z_col_off, hipStream_t st) {
-    if (rows) hipLaunchKernelGGL(bn_fwd_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, st, y, z, rows, cols, mean_inv, gamma, beta, ldz, z_col_off);
+hipError_t t_bn_fwd(const float* y, float* z, int64_t rows, int cols, const float* stats, int64_t rows_global, float* mean_inv,
+                    float* batch_mean, float* batch_var, const float* gamma, const float* beta, int64_t ldz, int z_col_off,
+                    hipStream_t st) {
+    if (rows)
+        hipLaunchKernelGGL(bn_fwd_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, st, y, z, rows, cols, stats,
+                           1.0f / (float)rows_global, mean_inv, batch_mean, batch_var, gamma, beta, ldz, z_col_off);
     return hipGetLastError();
 }
 hipError_t t_bn_bwd_reduce(const float* dz, int64_t lddz, int dz_col_off, const float* y, int64_t rows, int cols,
                            const float* mean_inv, float* sums, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(sums, 0, 2 * cols * sizeof(float), st);
-    if (e != hipSuccess || rows == 0) return e;
+    if (rows == 0) return hipSuccess;       // sums must arrive zeroed
     const int rpb = rows_per_block_for(rows);
     dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + rpb - 1) / rpb));
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, st, dz, lddz, dz_col_off, y, rows, cols, mean_inv, sums, rpb);
