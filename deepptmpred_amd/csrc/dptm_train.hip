@@ -575,29 +575,26 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
         T_TRY(hipEventRecord(t->ev_join[0][b], bs));
     }
     // struct branch (model.py:187-189)
-    T_TRY(t_gemm(ga(strct, 8, c.w(pm.strct.k), 128, c.w(pm.strct.b), t->sa, 128, 0, B, 8, 128), false, st));
-    T_TRY(t_swish_fwd(t->sa, t->sy, B * 128, st));
+    auto dense_swish = [&](GemmArgs g, float* act, int64_t lda) {     // pre-activation to g.out, swish of it to act
+        g.act_out = act; g.lda = lda;
+        return t_gemm(g, false, st);
+    };
+    T_TRY(dense_swish(ga(strct, 8, c.w(pm.strct.k), 128, c.w(pm.strct.b), t->sa, 128, 0, B, 8, 128), t->sy, 128));
     if ((rc = bn_train_fwd(c, t->sy, t->concat, kConcat, 192, B, 128, pm.strct.bn, t->smi))) return rc;
     T_TRY(t_dropout(t->concat + 192, B, 128, kConcat, 0, seed, 24 + 0, rt.dense, st));
     // ESM branch (model.py:191-194)
-    T_TRY(t_gemm(ga(esm, kEsm, c.w(pm.esm1.k), 512, c.w(pm.esm1.b), t->ea, 512, 0, B, kEsm, 512), false, st));
-    T_TRY(t_swish_fwd(t->ea, t->ey, B * 512, st));
+    T_TRY(dense_swish(ga(esm, kEsm, c.w(pm.esm1.k), 512, c.w(pm.esm1.b), t->ea, 512, 0, B, kEsm, 512), t->ey, 512));
     if ((rc = bn_train_fwd(c, t->ey, t->e1, 512, 0, B, 512, pm.esm1.bn, t->emi))) return rc;
     T_TRY(t_dropout(t->e1, B, 512, 512, 0, seed, 24 + 1, rt.dense, st));
-    T_TRY(t_gemm(ga(t->e1, 512, c.w(pm.esm2.k), 256, c.w(pm.esm2.b), t->e2a, 256, 0, B, 512, 256), false, st));
-    {   // swish into the concat columns 320..575
-        T_TRY(t_swish_fwd(t->e2a, t->d256a, B * 256, st));
-        T_TRY(t_copy_cols(t->concat, kConcat, 320, t->d256a, 256, 0, B, 256, false, st));
-    }
+    // swish straight into the concat columns 320..575
+    T_TRY(dense_swish(ga(t->e1, 512, c.w(pm.esm2.k), 256, c.w(pm.esm2.b), t->e2a, 256, 0, B, 512, 256), t->concat + 320, kConcat));
     for (int b = 0; b < 3; ++b) T_TRY(hipStreamWaitEvent(st, t->ev_join[0][b], 0));   // pooled branch outputs are in concat
     T_TRY(t_dropout(t->concat, B, kConcat, kConcat, 0, seed, 24 + 2, rt.dense, st));
     // trunk (model.py:200-205)
-    T_TRY(t_gemm(ga(t->concat, kConcat, c.w(pm.t1.k), 512, c.w(pm.t1.b), t->t1a, 512, 0, B, kConcat, 512), false, st));
-    T_TRY(t_swish_fwd(t->t1a, t->t1y, B * 512, st));
+    T_TRY(dense_swish(ga(t->concat, kConcat, c.w(pm.t1.k), 512, c.w(pm.t1.b), t->t1a, 512, 0, B, kConcat, 512), t->t1y, 512));
     if ((rc = bn_train_fwd(c, t->t1y, t->t1z, 512, 0, B, 512, pm.t1.bn, t->t1mi))) return rc;
     T_TRY(t_dropout(t->t1z, B, 512, 512, 0, seed, 24 + 3, rt.dense, st));
-    T_TRY(t_gemm(ga(t->t1z, 512, c.w(pm.t2.k), 256, c.w(pm.t2.b), t->t2a, 256, 0, B, 512, 256), false, st));
-    T_TRY(t_swish_fwd(t->t2a, t->t2y, B * 256, st));
+    T_TRY(dense_swish(ga(t->t1z, 512, c.w(pm.t2.k), 256, c.w(pm.t2.b), t->t2a, 256, 0, B, 512, 256), t->t2y, 256));
     if ((rc = bn_train_fwd(c, t->t2y, t->t2z, 256, 0, B, 256, pm.t2.bn, t->t2mi))) return rc;
     // ---------------- head, loss and its gradient (trainer.py:36-54)
     T_TRY(t_head_loss(t->t2z, c.w(pm.head.k), c.w(pm.head.b), labels, B, t->d_step, t->proba, t->d_loss, t->d256a,
