@@ -1,5 +1,5 @@
-"""CPU-restatement timings for the table in BASELINE.md section 4: batch 32 (Keras predict default) at
-1 thread and all threads, batch 4096 at all threads; median of 3 repeats, one warm-up pass excluded."""
+"""CPU-restatement timings: batch 32 (the Keras predict default) at 1 thread and at all threads, batch 4096
+at all threads; median of 3 repeats, one warm-up pass excluded."""
 import os, sys, time, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
