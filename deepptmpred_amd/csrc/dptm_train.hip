@@ -281,7 +281,7 @@ GemmTnArgs gt(const float* x, int64_t ldx, int xoff, const float* dy, int64_t ld
     GemmTnArgs a;
     a.x = x; a.ldx = ldx; a.x_col_off = xoff; a.dy = dy; a.ldy = ldy; a.dy_col_off = dyoff; a.dw = dw; a.ldw = ldw; a.db = db;
     a.m = m; a.k = k; a.n = n; a.shift = shift; a.wlen = wlen; a.rows_per_slab = 0;
-    a.slabs = 1; a.batch = 1; a.bx = a.bdy = a.bdw = a.bdb = 0;
+    a.slabs = 1; a.batch = 1; a.bx = a.bdy = a.bdw = a.bdb = 0; a.bshift_dir = 0;
     return a;
 }
 
@@ -295,10 +295,12 @@ int conv_fwd(const Ctx& c, const float* x, int kid, int bid, int taps, float* ou
 }
 // gradients of a conv: dK[t] += shift(x)^T dout, db += colsum(dout), dx (+)= sum_t shift_{-(t-1)}(dout) K[t]^T
 int conv_bwd(const Ctx& c, const float* x, const float* dout, int kid, int bid, int taps, float* dx, bool dx_acc, int64_t R, int wlen) {
-    for (int tp = 0; tp < taps; ++tp) {
-        const int sh = taps == 1 ? 0 : tp - 1;
-        T_TRY(t_gemm_tn(gt(x, 64, 0, dout, 64, 0, c.g(kid) + (size_t)tp * 64 * 64, 64, tp == 0 ? c.g(bid) : nullptr, R, 64, 64, sh,
-                           wlen), c.st));
+    {
+        GemmTnArgs g = gt(x, 64, 0, dout, 64, 0, c.g(kid), 64, c.g(bid), R, 64, 64, 0, wlen);
+        if (taps > 1) {      // the taps are independent products over shifted rows: one batched launch
+            g.batch = taps; g.bdw = 64 * 64; g.bshift_dir = 1;
+        }
+        T_TRY(t_gemm_tn(g, c.st));
     }
     if (dx) {
         GemmArgs a = ga(dout, 64, c.w(kid), 64, nullptr, dx, 64, 0, R, 64, 64, 0, wlen, dx_acc ? 1 : 0);

@@ -53,6 +53,7 @@ struct GemmTnArgs {
     int slabs;               // set by the launcher
     int batch;               // > 1: independent products in one launch: x + z*bx, dy + z*bdy, dw + z*bdw, db + z*bdb
     int64_t bx, bdy, bdw, bdb;
+    int bshift_dir;          // product z uses the row shift bshift_dir * (z - batch/2) instead of `shift` (taps of a convolution)
 };
 
 hipError_t t_gemm(const GemmArgs& a, bool nt, hipStream_t st);

@@ -277,7 +277,8 @@ __global__ __launch_bounds__(64) void tgemm_tn_kernel(GemmTnArgs p) {
     const int zslab = blockIdx.z - zb * p.slabs;
     if (p.batch > 1) {
         p.x += zb * p.bx; p.dy += zb * p.bdy; p.dw += zb * p.bdw;
-        if (p.db) p.db += zb * p.bdb;
+        if (p.db) p.db = p.bshift_dir ? (zb == 0 ? p.db : nullptr) : p.db + zb * p.bdb;   // taps share one bias
+        if (p.bshift_dir) p.shift = p.bshift_dir * (zb - p.batch / 2);
     }
     const int lane = threadIdx.x, h = lane >> 5, i = lane & 31;
     const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
@@ -330,7 +331,8 @@ __global__ __launch_bounds__(256) void tgemm_tn_lds_kernel(GemmTnArgs p) {
     const int zslab = blockIdx.z - zb * p.slabs;
     if (p.batch > 1) {
         p.x += zb * p.bx; p.dy += zb * p.bdy; p.dw += zb * p.bdw;
-        if (p.db) p.db += zb * p.bdb;
+        if (p.db) p.db = p.bshift_dir ? (zb == 0 ? p.db : nullptr) : p.db + zb * p.bdb;   // taps share one bias
+        if (p.bshift_dir) p.shift = p.bshift_dir * (zb - p.batch / 2);
     }
     __shared__ __attribute__((aligned(16))) float stage_all[4][2][32 * kStageStride];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
