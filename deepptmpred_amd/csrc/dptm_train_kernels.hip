@@ -717,13 +717,15 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const float* __restrict__ 
     for (int i = lane; i < wlen * wlen; i += 64) pb[i] = sp[i / wlen][i % wlen];
 }
 
-// dq, dk, dv from do (all [rows][64], head columns), with the saved probabilities.
+// dq, dk, dv from do (all [rows][64], head columns), with the saved probabilities.  One LDS image of the
+// W x W matrix serves twice (first P, then dS written over it row by row), which keeps the workgroup at
+// 25 KB of LDS; the price is that dP = dO V^T is formed twice per row.
 __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, const float* __restrict__ prob,
                                                       const float* __restrict__ d_o, float* __restrict__ dq,
                                                       float* __restrict__ dk, float* __restrict__ dv, int wlen) {
     __shared__ float sq[51][17], sk[51][17], sv[51][17], sdo[51][17];
-    __shared__ float sp[51][53], sds[51][53];   // odd row stride: row-per-lane and column-per-lane walks are both conflict-free
+    __shared__ float sp[51][53];   // odd row stride: row-per-lane and column-per-lane walks are both conflict-free
     const int b = blockIdx.x >> 2, hd = blockIdx.x & 3, lane = threadIdx.x;
     const int64_t base = (int64_t)b * wlen;
     for (int i = lane; i < wlen * 16; i += 64) {
@@ -737,21 +739,36 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
     const float* pb = prob + ((int64_t)b * 4 + hd) * wlen * wlen;
     for (int i = lane; i < wlen * wlen; i += 64) sp[i / wlen][i % wlen] = pb[i];
     __syncthreads();
-    if (lane < wlen) {   // query row `lane`: dP, dS and dQ
+    if (lane < wlen) {   // key row `lane`: dV = P^T dO
+        float av[16];
+#pragma unroll
+        for (int f = 0; f < 16; ++f) av[f] = 0.f;
+        for (int i = 0; i < wlen; ++i) {
+            const float p_ = sp[i][lane];
+#pragma unroll
+            for (int f = 0; f < 16; ++f) av[f] = fmaf(p_, sdo[i][f], av[f]);
+        }
+#pragma unroll
+        for (int f = 0; f < 16; ++f) dv[(base + lane) * 64 + 16 * hd + f] = av[f];
+    }
+    __syncthreads();
+    if (lane < wlen) {   // query row `lane`: dP, dS (over P) and dQ
         float dot = 0.f;
         for (int t = 0; t < wlen; ++t) {
             float dp = 0.f;
 #pragma unroll
             for (int f = 0; f < 16; ++f) dp = fmaf(sdo[lane][f], sv[t][f], dp);
-            sds[lane][t] = dp;
             dot = fmaf(dp, sp[lane][t], dot);
         }
         float acc[16];
 #pragma unroll
         for (int f = 0; f < 16; ++f) acc[f] = 0.f;
         for (int t = 0; t < wlen; ++t) {
-            const float ds = sp[lane][t] * (sds[lane][t] - dot);
-            sds[lane][t] = ds;
+            float dp = 0.f;
+#pragma unroll
+            for (int f = 0; f < 16; ++f) dp = fmaf(sdo[lane][f], sv[t][f], dp);
+            const float ds = sp[lane][t] * (dp - dot);
+            sp[lane][t] = ds;
 #pragma unroll
             for (int f = 0; f < 16; ++f) acc[f] = fmaf(ds, sk[t][f], acc[f]);
         }
@@ -759,23 +776,17 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const float* __restrict__ 
         for (int f = 0; f < 16; ++f) dq[(base + lane) * 64 + 16 * hd + f] = acc[f] * 0.25f;
     }
     __syncthreads();
-    if (lane < wlen) {   // key row `lane`: dK and dV
-        float ak[16], av[16];
+    if (lane < wlen) {   // key row `lane`: dK = dS^T Q
+        float ak[16];
 #pragma unroll
-        for (int f = 0; f < 16; ++f) ak[f] = av[f] = 0.f;
+        for (int f = 0; f < 16; ++f) ak[f] = 0.f;
         for (int i = 0; i < wlen; ++i) {
-            const float ds = sds[i][lane], p_ = sp[i][lane];
+            const float ds = sp[i][lane];
 #pragma unroll
-            for (int f = 0; f < 16; ++f) {
-                ak[f] = fmaf(ds, sq[i][f], ak[f]);
-                av[f] = fmaf(p_, sdo[i][f], av[f]);
-            }
+            for (int f = 0; f < 16; ++f) ak[f] = fmaf(ds, sq[i][f], ak[f]);
         }
 #pragma unroll
-        for (int f = 0; f < 16; ++f) {
-            dk[(base + lane) * 64 + 16 * hd + f] = ak[f] * 0.25f;
-            dv[(base + lane) * 64 + 16 * hd + f] = av[f];
-        }
+        for (int f = 0; f < 16; ++f) dk[(base + lane) * 64 + 16 * hd + f] = ak[f] * 0.25f;
     }
 }
 
