@@ -634,31 +634,50 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ inv_in, const float* __restrict__ g,
                                                      float* __restrict__ dsum, float* __restrict__ dg,
                                                      float* __restrict__ dbeta, int64_t rows, int rows_per_block) {
-    __shared__ float sg[4][64], sb[4][64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // 16 lanes per row, four features each (16-byte accesses): a wavefront takes four rows per trip and the
+    // two row sums cost four exchange steps instead of six
+    __shared__ f32x4 sg[16][16], sb[16][16];
+    const int sub = threadIdx.x & 15, slot = threadIdx.x >> 4;      // feature group, row slot 0..15
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(rows, r0 + rows_per_block);
-    const float gl = g[lane];
-    float ag = 0.f, ab = 0.f;
-    for (int64_t r = r0 + w; r < r1; r += 4) {
-        const float d = dy[r * 64 + lane], xh = xhat[r * 64 + lane];
-        const float dg_ = d * gl;
-        float s1 = dg_, s2 = dg_ * xh;
+    const f32x4 gl = *reinterpret_cast<const f32x4*>(g + 4 * sub);
+    f32x4 ag = {0.f, 0.f, 0.f, 0.f}, ab = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t rb = r0; rb < r1; rb += 16) {
+        const int64_t r = rb + slot;
+        const bool ok = r < r1;
+        f32x4 d = {0.f, 0.f, 0.f, 0.f}, xh = d;
+        if (ok) {
+            d = *reinterpret_cast<const f32x4*>(dy + r * 64 + 4 * sub);
+            xh = *reinterpret_cast<const f32x4*>(xhat + r * 64 + 4 * sub);
+        }
+        const f32x4 dgv = d * gl;
+        float s1 = (dgv[0] + dgv[1]) + (dgv[2] + dgv[3]);
+        float s2 = (dgv[0] * xh[0] + dgv[1] * xh[1]) + (dgv[2] * xh[2] + dgv[3] * xh[3]);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
+        for (int o = 8; o > 0; o >>= 1) {
             s1 += __shfl_xor(s1, o);
             s2 += __shfl_xor(s2, o);
         }
-        dsum[r * 64 + lane] = inv_in[r] * (dg_ - s1 * (1.0f / 64.0f) - xh * s2 * (1.0f / 64.0f));
+        if (ok) {
+            const float inv = inv_in[r];
+            *reinterpret_cast<f32x4*>(dsum + r * 64 + 4 * sub) = inv * (dgv - s1 * (1.0f / 64.0f) - xh * (s2 * (1.0f / 64.0f)));
+        }
         ag += d * xh;
         ab += d;
     }
-    sg[w][lane] = ag;
-    sb[w][lane] = ab;
+    sg[slot][sub] = ag;
+    sb[slot][sub] = ab;
     __syncthreads();
-    if (w == 0) {
-        atomicAdd(dg + lane, sg[0][lane] + sg[1][lane] + sg[2][lane] + sg[3][lane]);
-        atomicAdd(dbeta + lane, sb[0][lane] + sb[1][lane] + sb[2][lane] + sb[3][lane]);
+    if (threadIdx.x < 64) {
+        const int f4 = threadIdx.x >> 2, e = threadIdx.x & 3;
+        float tg = 0.f, tb = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            tg += sg[q][f4][e];
+            tb += sb[q][f4][e];
+        }
+        atomicAdd(dg + threadIdx.x, tg);
+        atomicAdd(dbeta + threadIdx.x, tb);
     }
 }
 
