@@ -194,7 +194,11 @@ __global__ __launch_bounds__(512) void tgemm_lds_kernel(GemmArgs p) {
                 g[i] = *reinterpret_cast<const f32x4*>(p.x + tp * p.x_tap_stride + rr * p.ldx + 64 * kb + ccol);
         }
     };
-    for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntile; tile += (int64_t)gridDim.x * 8) {
+    const int64_t tstep = (int64_t)gridDim.x * 8;
+    int64_t tile = (int64_t)blockIdx.x * 8 + wave;
+    f32x4 g[8], gn[8];
+    if (tile < ntile) fetch(g, tile * 32, 0);
+    for (; tile < ntile; tile += tstep) {
         const int64_t r0 = tile * 32;
         const int64_t r = r0 + j;
         f32x16 acc[2];
@@ -205,10 +209,11 @@ __global__ __launch_bounds__(512) void tgemm_lds_kernel(GemmArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     acc[t][4 * g + e] = p.bias ? p.bias[c0 + 32 * t + 8 * g + 4 * h + e] : 0.f;
-        f32x4 g[8], gn[8];
-        fetch(g, r0, 0);
         for (int seg = 0; seg < nseg; ++seg) {
+            // the next segment -- of this tile, or the first one of the wavefront's next tile -- is requested now
+            const bool more = seg + 1 < nseg || tile + tstep < ntile;
             if (seg + 1 < nseg) fetch(gn, r0, seg + 1);
+            else if (tile + tstep < ntile) fetch(gn, (tile + tstep) * 32, 0);
             const int tp = seg / kblocks;
             const int shift = p.taps > 1 ? p.tap_dir * (tp - p.taps / 2) : p.shift;
             const bool ok = row_ok(r, shift, p.m, p.wlen);
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(512) void tgemm_lds_kernel(GemmArgs p) {
                     mfma2(acc[1], a1[e], b[v][e]);
                 }
             }
-            if (seg + 1 < nseg) {
+            if (more) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) g[i] = gn[i];
             }
