@@ -439,6 +439,19 @@ __global__ void swish_bwd_kernel(const float* __restrict__ a, const float* __res
         da[i] = dy[i] * (s * (1.0f + v * (1.0f - s)));
     }
 }
+// n4 groups of four floats, 16-byte aligned
+__global__ void swish_bwd4_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ dy, f32x4* __restrict__ da, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = a[i], g = dy[i];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float s = sigmoidf_(v[e]);
+            o[e] = g[e] * (s * (1.0f + v[e] * (1.0f - s)));
+        }
+        da[i] = o;
+    }
+}
 
 __global__ void add_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -471,6 +484,26 @@ __global__ void dropout_kernel(float* __restrict__ x, const float* __restrict__ 
         const unsigned idx = wlen_spatial ? (unsigned)((r / wlen_spatial) * cols + c) : (unsigned)i;
         const float v = src[r * ld + c];
         x[r * ld + c] = hash_u32(seed, stream, idx) >= thr ? v * scale : 0.f;
+    }
+}
+
+// The same for the common shape (cols a multiple of 4, 16-byte aligned rows, fewer than 2^31 elements): four
+// columns per thread, 32-bit index arithmetic.  Element indices -- and with them the masks -- are unchanged.
+__global__ void dropout4_kernel(float* __restrict__ x, const float* __restrict__ src, int rows, int cols, int ld,
+                                int wlen_spatial, const unsigned* __restrict__ step_params, unsigned stream, unsigned thr,
+                                float scale) {
+    const unsigned seed = step_params[kStepSeed];
+    const int c4n = cols >> 2;
+    const int total = rows * c4n;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int r = i / c4n;
+        const int c = (i - r * c4n) << 2;
+        const unsigned base = wlen_spatial ? (unsigned)((r / wlen_spatial) * cols + c) : (unsigned)(r * cols + c);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)r * ld + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = hash_u32(seed, stream, base + e) >= thr ? v[e] * scale : 0.f;
+        *reinterpret_cast<f32x4*>(x + (int64_t)r * ld + c) = o;
     }
 }
 
@@ -1073,7 +1106,12 @@ hipError_t t_swish_fwd(const float* a, float* y, int64_t n, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t t_swish_bwd(const float* a, const float* dy, float* da, int64_t n, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(swish_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, a, dy, da, n);
+    if (n == 0) return hipSuccess;
+    if (n % 4 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(da)) & 15) == 0)
+        hipLaunchKernelGGL(swish_bwd4_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(a),
+                           reinterpret_cast<const f32x4*>(dy), reinterpret_cast<f32x4*>(da), n / 4);
+    else
+        hipLaunchKernelGGL(swish_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, st, a, dy, da, n);
     return hipGetLastError();
 }
 hipError_t t_add(float* dst, const float* src, int64_t n, hipStream_t st) {
@@ -1095,7 +1133,14 @@ hipError_t t_dropout(float* x, int64_t rows, int cols, int64_t ld, int wlen_spat
     }
     double t = (double)rate * 4294967296.0;
     const unsigned thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
-    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, st, x, src ? src : x, rows, cols, ld, wlen_spatial,
+    const float* in = src ? src : x;
+    if (cols % 4 == 0 && ld % 4 == 0 && rows * cols < (int64_t)1 << 31 && rows * ld < (int64_t)1 << 31 &&
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(in)) & 15) == 0) {
+        hipLaunchKernelGGL(dropout4_kernel, dim3(grid_for(rows * cols / 4)), dim3(256), 0, st, x, in, (int)rows, cols, (int)ld,
+                           wlen_spatial, step_params, stream, thr, 1.0f / (1.0f - rate));
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, st, x, in, rows, cols, ld, wlen_spatial,
                        step_params, stream, thr, 1.0f / (1.0f - rate));
     return hipGetLastError();
 }
