@@ -570,6 +570,49 @@ __global__ __launch_bounds__(256) void colsum2_kernel(const float* __restrict__ 
     }
 }
 
+// The 64-column case of the two column-sum kernels (the BatchNorms of the sequence branches, where the rows are
+// many): 16 lanes per row with 16-byte loads, 16 rows per trip, partial sums met in LDS.
+// MODE 0: stats = [sum x | sum x^2];  MODE 1: sums = [sum dz | sum dz * xhat] with xhat from y, mean, inv.
+template <int MODE>
+__global__ __launch_bounds__(256) void colsum64_kernel(const float* __restrict__ x, int64_t ldx, int x_col_off,
+                                                       const float* __restrict__ y, const float* __restrict__ mean_inv,
+                                                       int64_t rows, float* __restrict__ stats, int rows_per_block) {
+    __shared__ f32x4 p1[16][16], p2[16][16];
+    const int sub = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(rows, r0 + rows_per_block);
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, inv = mu;
+    if (MODE == 1) {
+        mu = *reinterpret_cast<const f32x4*>(mean_inv + 4 * sub);
+        inv = *reinterpret_cast<const f32x4*>(mean_inv + 64 + 4 * sub);
+    }
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    for (int64_t r = r0 + slot; r < r1; r += 16) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + x_col_off + 4 * sub);
+        s1 += v;
+        if (MODE == 0) {
+            s2 += v * v;
+        } else {
+            const f32x4 yy = *reinterpret_cast<const f32x4*>(y + r * 64 + 4 * sub);
+            s2 += v * (yy - mu) * inv;
+        }
+    }
+    p1[slot][sub] = s1;
+    p2[slot][sub] = s2;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int f4 = threadIdx.x >> 2, e = threadIdx.x & 3;
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            t1 += p1[q][f4][e];
+            t2 += p2[q][f4][e];
+        }
+        atomicAdd(stats + threadIdx.x, t1);
+        atomicAdd(stats + 64 + threadIdx.x, t2);
+    }
+}
+
 // z = (y - mean) * inv * gamma + beta with mean / inv = rsqrt(var + eps) taken straight from the column sums
 // (stats = [sum | sum of squares] over inv_rows^-1 rows).  The first workgroup also leaves mean | inv in
 // mean_inv for the backward pass and the batch mean / (biased) variance for the moving-statistics update.
@@ -1164,6 +1207,11 @@ static inline int rows_per_block_for(int64_t rows) {
 hipError_t t_colsum2(const float* x, const float* y, int64_t rows, int cols, float* stats, hipStream_t st) {
     if (rows == 0) return hipSuccess;
     const int rpb = rows_per_block_for(rows);
+    if (cols == 64 && !y && rows >= 1024 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        hipLaunchKernelGGL(colsum64_kernel<0>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st, x, (int64_t)64, 0,
+                           nullptr, nullptr, rows, stats, rpb);
+        return hipGetLastError();
+    }
     dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + rpb - 1) / rpb));
     hipLaunchKernelGGL(colsum2_kernel, grid, dim3(256), 0, st, x, y, rows, cols, (int64_t)cols, stats, rpb);
     return hipGetLastError();
@@ -1180,6 +1228,12 @@ hipError_t t_bn_bwd_reduce(const float* dz, int64_t lddz, int dz_col_off, const 
                            const float* mean_inv, float* sums, hipStream_t st) {
     if (rows == 0) return hipSuccess;       // sums must arrive zeroed
     const int rpb = rows_per_block_for(rows);
+    if (cols == 64 && rows >= 1024 && lddz % 4 == 0 && dz_col_off % 4 == 0 &&
+        ((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(mean_inv)) & 15) == 0) {
+        hipLaunchKernelGGL(colsum64_kernel<1>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st, dz, lddz, dz_col_off, y,
+                           mean_inv, rows, sums, rpb);
+        return hipGetLastError();
+    }
     dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + rpb - 1) / rpb));
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, st, dz, lddz, dz_col_off, y, rows, cols, mean_inv, sums, rpb);
     return hipGetLastError();
