@@ -402,6 +402,26 @@ __global__ __launch_bounds__(256) void tgemm_tn_lds_kernel(GemmTnArgs p) {
             }
         }
     }
+    // The four wavefronts' partial tiles meet in LDS (the stages are free now) and one of them adds the block's sum
+    // to dW: every float atomic lands on the same 64 x 64 values, so a quarter of them is a quarter of the queue.
+    __syncthreads();
+    float* red = &stage_all[0][0][0];                       // [3][64 regs][64 lanes]
+    bsum0 += __shfl_xor(bsum0, 32);                         // both half-waves now hold the sum over their row pairs
+    bsum1 += __shfl_xor(bsum1, 32);
+    if (wave > 0) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) red[((wave - 1) * 64 + (a * 2 + b) * 16 + rg) * 64 + lane] = acc[a][b][rg];
+        if (h == 0) {
+            red[3 * 64 * 64 + ((wave - 1) * 2 + 0) * 32 + i] = bsum0;
+            red[3 * 64 * 64 + ((wave - 1) * 2 + 1) * 32 + i] = bsum1;
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
     // D[row = k][col = n]: lane holds column i, rows (reg&3) + 8*(reg>>2) + 4*h of each 32 x 32 tile
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -409,15 +429,17 @@ __global__ __launch_bounds__(256) void tgemm_tn_lds_kernel(GemmTnArgs p) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int rg = 0; rg < 16; ++rg) {
+                const int slot = (a * 2 + b) * 16 + rg;
+                const float v = acc[a][b][rg] + red[(0 * 64 + slot) * 64 + lane] + red[(1 * 64 + slot) * 64 + lane] +
+                                red[(2 * 64 + slot) * 64 + lane];
                 const int k = k0 + 32 * a + (rg & 3) + 8 * (rg >> 2) + 4 * h;
-                atomicAdd(p.dw + (int64_t)k * p.ldw + n0 + 32 * b + i, acc[a][b][rg]);
+                atomicAdd(p.dw + (int64_t)k * p.ldw + n0 + 32 * b + i, v);
             }
     if (p.db && blockIdx.x == 0) {
-        bsum0 += __shfl_xor(bsum0, 32);
-        bsum1 += __shfl_xor(bsum1, 32);
         if (h == 0) {
-            atomicAdd(p.db + n0 + i, bsum0);
-            atomicAdd(p.db + n0 + 32 + i, bsum1);
+            const float* rb = red + 3 * 64 * 64;
+            atomicAdd(p.db + n0 + i, bsum0 + rb[0 * 32 + i] + rb[2 * 32 + i] + rb[4 * 32 + i]);
+            atomicAdd(p.db + n0 + 32 + i, bsum1 + rb[1 * 32 + i] + rb[3 * 32 + i] + rb[5 * 32 + i]);
         }
     }
 }
