@@ -1115,7 +1115,7 @@ hipError_t t_gemm(const GemmArgs& a, bool nt, hipStream_t st) {
         }
         const int64_t tiles8 = (a.m + 255) / 256;
         const unsigned ycols = (unsigned)(a.cols / 64);
-        int64_t gx = 512 / ycols;                     // about two workgroups per CU over all column tiles
+        int64_t gx = 256 / ycols;                     // one workgroup per CU over all column tiles (measured best of 128..2048)
         if (gx < 1) gx = 1;
         if (gx > tiles8) gx = tiles8;
         dim3 grid((unsigned)gx, ycols, (unsigned)(a.batch > 1 ? a.batch : 1));
