@@ -10,18 +10,31 @@ through the C ABI (dptm_score_device).  For N > 1 every rank scores its own S si
 (sites are independent: no data-path collective), so scaling is weak and `value` is the
 whole-job rate.  Rank 0 prints ONE JSON line.
 
-Also reported on the same line:
+`--gpus N` with N > 1 outside a launcher starts the N ranks itself (fresh child processes
+under torch.distributed.run, before this process touches a GPU) and relays rank 0's line.
+
+Also reported on the same line (N = 1):
   roofline     the dominant kernel (fused W=51 sequence branch): algorithmic FLOPs per
                launch / its average launch time, measured with HIP events on the launch
                stream in an extra profiled step, against the dense fp32 MFMA peak.
   cpu_baseline the torch-CPU restatement of the reference graph (oracle/torch_ref.py)
                timed on a bounded sample of the same workload on the host cores.
+  variants     the other arithmetic modes on the same resident inputs.
+  streamed_from_host  the same model with NumPy arrays in and out (PCIe included).
+  proteome     many small proteins per call through dptm_score_proteins_device: window
+               assembly + ESM row gather on the device (BASELINE north_star 1 and 4).
+  sweep        BASELINE config 4 on one GPU: 17 weight sets over 262,144 resident sites.
+  train        BASELINE config 5 on one GPU: training step at batch 64 and 8192.
+Other modes (`--types T`, `--train`, `--proteome`) print their own single line and shard over
+ranks the same way.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,13 +48,15 @@ import torch  # noqa: E402
 FLOPS_PER_SITE = 31_234_816          # 2*MAC of every contraction of the forward graph
 FLOPS_BRANCH = {21: 5_564_160, 33: 8_946_432, 51: 14_296_320}
 BYTES_PER_SITE = 5_261               # 1280*4 + 8*4 + 105 + 4
+ASSEMBLE_BYTES_PER_SITE = 105 + 4 + 4 + 4   # three windows + esm row index written, position + protein id read
 PEAK_F32_MFMA_TFLOPS = 157.3         # dense fp32 matrix peak of MI355X
 PEAK_F16_MFMA_TFLOPS = 2500.0        # dense f16 / bf16 matrix peak (no sparsity)
 PEAK_MFMA = {"f32": PEAK_F32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS, "f16": PEAK_F16_MFMA_TFLOPS,
              "bf16": PEAK_F16_MFMA_TFLOPS}
 KERNEL_NAME = {"f32": "branch_kernel<51>", "f16x3": "branch_kernel_h<51,f16x3>", "f16": "branch_kernel_h<51,f16>",
                "bf16": "branch_kernel_h<51,bf16>"}
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r2_pmc_traffic.json", "r1_pmc_traffic.json")]
+PEAK_HBM_GBS = 8000.0
 
 
 def measured_traffic(precision: str, sites_per_launch: float):
@@ -49,16 +64,107 @@ def measured_traffic(precision: str, sites_per_launch: float):
     (profiles/collect_pmc.sh: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction for 16 B/lane
     reads).  PMC counters cannot be read from inside this process; null when no pass was recorded
     for this precision and launch size."""
-    try:
-        with open(TRAFFIC_FILE) as f:
-            rec = json.load(f).get(precision)
-    except (OSError, ValueError):
-        return None
-    if not rec or abs(rec.get("sites_per_launch", 0) - sites_per_launch) > 0.5:
-        return None
-    return rec.get("traffic_bytes_per_launch")
-PEAK_HBM_GBS = 8000.0
+    for path in TRAFFIC_FILES:
+        try:
+            with open(path) as f:
+                rec = json.load(f).get(precision)
+        except (OSError, ValueError):
+            continue
+        if rec and abs(rec.get("sites_per_launch", 0) - sites_per_launch) <= 0.5:
+            return rec.get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT)
+    return None, None
 
+
+# ------------------------------------------------------------------------------------ ranks
+
+def self_launch(args) -> None:
+    """`--gpus N` (N > 1) outside a launcher: this process has imported torch but touched no device.
+    Start N fresh ranks as children, relay rank 0's JSON line and the launcher's return code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    lines = [l for l in proc.stdout.splitlines() if l.strip()]
+    found = [l for l in lines if l.lstrip().startswith("{")]
+    for l in lines:
+        if l not in found:
+            print(l, file=sys.stderr)
+    if found:
+        print(found[-1])
+    sys.stdout.flush()
+    sys.exit(proc.returncode if proc.returncode else (0 if found else 1))
+
+
+class Ranks:
+    """One process per GPU.  RCCL carries the barrier and the max-over-ranks reduction; under
+    DPTM_BENCH_REHEARSAL=1 (multi-rank rehearsal on a one-GPU box) every rank sits on GPU 0 and gloo
+    does (RCCL refuses two ranks on one device)."""
+
+    def __init__(self, args):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={self.world} ranks")
+        self.rehearsal = os.environ.get("DPTM_BENCH_REHEARSAL") == "1"
+        if self.rehearsal:
+            self.local = 0
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.rehearsal:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                        device_id=torch.device(f"cuda:{self.local}"))
+            self.dist = dist
+        torch.cuda.set_device(self.local)
+        self.dev = torch.device(f"cuda:{self.local}")
+        self.rdev = torch.device("cpu") if self.rehearsal else self.dev      # where reduced scalars live
+
+    def barrier(self) -> None:
+        torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, v: float) -> float:
+        if self.dist is None:
+            return v
+        t = torch.tensor([v], device=self.rdev, dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, v: float) -> float:
+        if self.dist is None:
+            return v
+        t = torch.tensor([v], device=self.rdev, dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def timed(self, step, steps: int, warmup: int) -> float:
+        """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks (seconds)."""
+        for i in range(warmup):
+            step(i)
+        self.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def finish(self) -> None:
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------ inputs
 
 def device_inputs(n: int, seed: int, dev: torch.device):
     """Same distributions as deepptmpred_amd.spec.synthetic_inputs, generated on the GPU."""
@@ -74,13 +180,21 @@ def device_inputs(n: int, seed: int, dev: torch.device):
     wide[left | right] = 20
     toks = [wide[:, 25 - h:25 + h + 1].contiguous() for h in (10, 16, 25)]
     del left, right
-    esm = torch.empty((n, 1280), device=dev, dtype=torch.float32)
+    return toks + [device_struct(n, g, dev), device_esm(n, g, dev)]
+
+
+def device_esm(rows: int, g, dev):
+    esm = torch.empty((rows, 1280), device=dev, dtype=torch.float32)
     step = 1 << 17
-    for s in range(0, n, step):   # chunked: keeps the temporaries small
-        e = min(n, s + step)
+    for s in range(0, rows, step):   # chunked: keeps the temporaries small
+        e = min(rows, s + step)
         blk = torch.randn((e - s, 1280), generator=g, device=dev) * 0.27
         heavy = torch.rand((e - s, 1280), generator=g, device=dev) < 0.01
         esm[s:e] = torch.where(heavy, blk * 10.0, blk)
+    return esm
+
+
+def device_struct(n: int, g, dev):
     st = torch.zeros((n, 8), device=dev, dtype=torch.float32)
     st[:, 0] = torch.rand(n, generator=g, device=dev) * 250
     st[:, 1] = torch.rand(n, generator=g, device=dev) * 360 - 180
@@ -89,11 +203,14 @@ def device_inputs(n: int, seed: int, dev: torch.device):
     st[torch.arange(n, device=dev), 3 + ss] = 1.0
     st[:, 6] = torch.rand(n, generator=g, device=dev) * 80 + 20
     st[:, 7] = torch.rand(n, generator=g, device=dev) * 80 + 20
-    return toks + [st, esm]
+    return st
 
 
-def cpu_baseline(weights, budget_s: float = 15.0):
-    """Times oracle/torch_ref.py (fp32, batch 4096) on the host cores for ~budget_s."""
+# ------------------------------------------------------------------------------------ CPU leg
+
+def cpu_baseline(weights, budget_s: float = 12.0):
+    """Times oracle/torch_ref.py (fp32) on the host cores: `value` = batch 4096 on all threads for
+    ~budget_s; `grid` = medians of 3 repeats for batch {32, 4096} x threads {1, all} on small samples."""
     from deepptmpred_amd import spec
     from oracle.torch_ref import TorchRef
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
@@ -110,37 +227,41 @@ def cpu_baseline(weights, budget_s: float = 15.0):
     t0 = time.perf_counter()
     ref.predict(x, batch_size=4096)
     dt = time.perf_counter() - t0
+    grid = {}
+    for th in sorted({1, threads}):
+        torch.set_num_threads(th)
+        for batch, m in ((32, 512), (4096, 4096)):
+            xs = [a[:m] for a in x]
+            ref.predict(xs, batch_size=batch)
+            reps = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                ref.predict(xs, batch_size=batch)
+                reps.append(m / (time.perf_counter() - t1))
+            grid[f"batch{batch}_threads{th}"] = {"sites_per_s": float(np.median(reps)), "sites": m}
+    torch.set_num_threads(threads)
     return {"value": n / dt, "unit": "sites/s", "cores": threads, "kind": "port",
-            "sample": f"{n} synthetic sites, torch-CPU fp32 restatement, batch 4096, {dt:.1f} s"}
+            "sample": f"{n} synthetic sites, torch-CPU fp32 restatement, batch 4096, {dt:.1f} s",
+            "grid": grid, "host_cpu_count": os.cpu_count()}
 
 
-def train_main(args) -> None:
-    """--train: fwd + bwd + gradient all-reduce + AdamW per step on synthetic imbalanced
-    sites (labels ~ Bernoulli(0.042), the phosphorylation ratio), one replica per GPU."""
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
-    torch.cuda.set_device(local)
-    dev = torch.device(f"cuda:{local}")
+# ------------------------------------------------------------------------------------ training step
+
+def measure_train(R: Ranks, batch: int, steps: int, warmup: int) -> dict:
+    """fwd + bwd + gradient all-reduce + AdamW per step on synthetic imbalanced sites (labels ~
+    Bernoulli(0.042), the phosphorylation ratio), one replica per GPU, dropout on."""
     from deepptmpred_amd import _native, spec
     from deepptmpred_amd.training import NativeBackend
-    b = args.batch
-    backend = NativeBackend(spec.synthetic_weights(7), device=local, max_batch=b)
-    x = device_inputs(b, 99 + rank, dev)
+    dev, rank, world = R.dev, R.rank, R.world
+    backend = NativeBackend(spec.synthetic_weights(7), device=R.local, max_batch=batch)
+    x = device_inputs(batch, 99 + rank, dev)
     g = torch.Generator(device=dev)
     g.manual_seed(5 + rank)
-    labels = (torch.rand(b, generator=g, device=dev) < 0.042).to(torch.int32)
-    n_pos = torch.tensor([float(labels.sum().item())], device=dev)
-    if dist is not None:
-        dist.all_reduce(n_pos)
+    labels = (torch.rand(batch, generator=g, device=dev) < 0.042).to(torch.int32)
+    n_pos = int(R.sum_over_ranks(float(labels.sum().item())))
     o = _native.TrainOpts()
     o.rate_embed, o.rate_conv, o.rate_tb, o.rate_dense = 1e-4, 0.3, 0.1, 0.3
-    o.n_global, o.n_pos_global, o.l2, o.l2_scale = b * world, int(n_pos.item()), 1e-4, 1.0 / world
+    o.n_global, o.n_pos_global, o.l2, o.l2_scale = batch * world, n_pos, 1e-4, 1.0 / world
     # one explicit stream for the whole step: the library's kernels, RCCL's all-reduce (which orders itself
     # after torch's current stream) and the optimizer update are then stream-ordered without host syncs
     tstream = torch.cuda.Stream(device=dev)
@@ -151,105 +272,73 @@ def train_main(args) -> None:
         o.seed = i * 1000003 + rank
         with torch.cuda.stream(tstream):
             backend.trainer.forward_backward(x[0].data_ptr(), x[1].data_ptr(), x[2].data_ptr(), x[3].data_ptr(),
-                                             x[4].data_ptr(), labels.data_ptr(), b, o, False, st)
-            if dist is not None:
+                                             x[4].data_ptr(), labels.data_ptr(), batch, o, False, st)
+            if R.dist is not None:
                 backend.allreduce_grads()
             backend.trainer.apply(5e-4, 1e-4, 1.0, 1.0 / world, st)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    elapsed = R.timed(step, steps, warmup)
+    w = backend.trainer.get_weights()
+    assert np.isfinite(w).all()
+    backend.close()
+    value = world * batch * steps / elapsed
+    tf = value / world * 3 * FLOPS_PER_SITE / 1e12
+    return {"batch_per_gpu": batch, "steps": steps, "ms_per_step": elapsed / steps * 1e3, "sites_per_s": value,
+            "tflops_per_gpu": tf, "frac_of_f32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS}
 
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if rank == 0:
-        value = world * b * args.steps / elapsed
+
+def train_main(args, R: Ranks) -> None:
+    m = measure_train(R, args.batch, args.steps, args.warmup)
+    if R.rank == 0:
         print(json.dumps({
-            "metric": "training sites/sec (fwd+bwd+all-reduce+AdamW)", "value": value, "unit": "sites/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "metric": "training sites/sec (fwd+bwd+all-reduce+AdamW)", "value": m["sites_per_s"], "unit": "sites/s",
+            "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic imbalanced sites (4.2% positive), seeded synthetic weights",
-            "config": {"workload": "config 5: main.py-style training step", "batch_per_gpu": b,
-                       "parallelism": f"dp{world} (one flat 6.6 MB fp32 gradient all-reduce per step)"},
-            "whole_path": {"tflops": value / world * 3 * FLOPS_PER_SITE / 1e12}}))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+            "config": {"workload": "config 5: main.py-style training step", "batch_per_gpu": args.batch,
+                       "parallelism": f"dp{R.world} (one flat 6.6 MB fp32 gradient all-reduce per step)"},
+            "roofline": {"bound": "mfma", "kernel": "whole step (forward + backward + AdamW)",
+                         "achieved": m["tflops_per_gpu"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": m["frac_of_f32_mfma_peak"], "traffic": None,
+                         "flops_per_site": 3 * FLOPS_PER_SITE},
+            "whole_path": {"tflops": m["tflops_per_gpu"]}}))
+    R.finish()
 
 
-def sweep_main(args) -> None:
-    """--types T: the same resident sites scored by T weight sets (BASELINE config 4: every PTM type has
-    its own model, predict.py:119-137).  Sites are sharded over ranks, every rank holds all T models
-    (6.5 MB each), inputs are read T times from HBM and never re-uploaded.  `value` counts
-    (site, type) scorings per second; rank 0 also times the host-array form (one upload per pass
-    shared by all types) on a bounded sample."""
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
-    torch.cuda.set_device(local)
-    dev = torch.device(f"cuda:{local}")
+# ------------------------------------------------------------------------------------ 17-type sweep
+
+def measure_sweep(R: Ranks, T: int, n: int, steps: int, warmup: int, precision: str, x=None) -> dict:
+    """The same resident sites scored by T weight sets (every PTM type has its own model,
+    predict.py:119-137).  Sites are sharded over ranks, every rank holds all T models (6.5 MB each),
+    inputs are read T times from HBM and never re-uploaded.  Counts (site, type) scorings per second;
+    rank 0 also times the host-array form (one upload per pass shared by all types)."""
     from deepptmpred_amd import spec
     from deepptmpred_amd.model import Model
     from deepptmpred_amd.sharding import predict_all_types
-
-    T = args.types
-    models = {f"type{k:02d}": Model(spec.synthetic_weights(100 + k), device=local) for k in range(T)}
+    dev = R.dev
+    models = {f"type{k:02d}": Model(spec.synthetic_weights(100 + k), device=R.local) for k in range(T)}
     for m in models.values():
-        m.scorer.set_precision(args.precision)
-    n = args.sites
-    x = device_inputs(n, 1234 + rank, dev)
+        m.scorer.set_precision(precision)
+    if x is None:
+        x = device_inputs(n, 1234 + R.rank, dev)
     outs = [torch.empty((n, 2), device=dev, dtype=torch.float32) for _ in range(T)]
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream().cuda_stream
     ptrs = [t.data_ptr() for t in x]
 
-    def step():
+    def step(_i):
         for m, o in zip(models.values(), outs):
             m.scorer.score_device(ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], n, o.data_ptr(), stream)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = R.timed(step, steps, warmup)
     for o in outs:
         chk = o[:: max(1, n // 1024)].cpu().numpy()
         assert np.isfinite(chk).all() and np.abs(chk.sum(axis=1) - 1).max() < 1e-5
     # different weight sets must give different answers (the models are really distinct)
-    assert float((outs[0][:1024] - outs[-1][:1024]).abs().max().item()) > 0 or T == 1
+    assert T == 1 or float((outs[0][:1024] - outs[-1][:1024]).abs().max().item()) > 0
 
     streamed = None
-    if rank == 0:
+    if R.rank == 0:
         m = min(n, 262144)
         hx = spec.synthetic_inputs(m, 77)
         predict_all_types(models, [a[:4096] for a in hx])            # warm-up: pinned buffers, first launches
@@ -259,23 +348,131 @@ def sweep_main(args) -> None:
         assert len(res) == T
         streamed = {"site_types_per_s_one_gpu": m * T / dt, "sites": m,
                     "note": "host arrays in, host arrays out; one upload per pass shared by all types"}
-    barrier()
-    if rank == 0:
-        value = world * n * T * args.steps / elapsed
+    R.barrier()
+    for m in models.values():
+        m.close()
+    value = R.world * n * T * steps / elapsed
+    return {"types": T, "sites_per_gpu": n, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+            "site_types_per_s": value, "sites_per_s_all_types": value / T,
+            "tflops_per_gpu": value / R.world * FLOPS_PER_SITE / 1e12,
+            "frac_of_mfma_peak": value / R.world * FLOPS_PER_SITE / 1e12 / PEAK_MFMA[precision],
+            "streamed_from_host": streamed}
+
+
+def sweep_main(args, R: Ranks) -> None:
+    T, n = args.types, args.sites
+    m = measure_sweep(R, T, n, args.steps, args.warmup, args.precision)
+    if R.rank == 0:
         print(json.dumps({
-            "metric": "windows x PTM types scored/sec", "value": value, "unit": "site-types/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "metric": "windows x PTM types scored/sec", "value": m["site_types_per_s"], "unit": "site-types/s",
+            "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
             "data": "synthetic (device-generated sites, seeded synthetic weight sets 100..)",
             "config": {"workload": f"config 4: {n:,} resident sites per GPU x {T} weight sets, {args.precision}, "
-                                   f"{world} x MI355X", "sites_per_gpu": n, "types": T,
-                       "parallelism": f"dp{world} (sites sharded, every rank holds all {T} models, no collective)"},
-            "whole_path": {"tflops": value / world * FLOPS_PER_SITE / 1e12,
-                           "sites_per_s_all_types": value / T},
-            "streamed_from_host": streamed}))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+                                   f"{R.world} x MI355X", "sites_per_gpu": n, "types": T,
+                       "parallelism": f"dp{R.world} (sites sharded, every rank holds all {T} models, no collective)"},
+            "whole_path": {"tflops": m["tflops_per_gpu"], "sites_per_s_all_types": m["sites_per_s_all_types"]},
+            "streamed_from_host": m["streamed_from_host"]}))
+    R.finish()
+
+
+# ------------------------------------------------------------------------------------ proteome
+
+def synthetic_proteome(n_proteins: int, seed: int, dev: torch.device, max_sites: int = 0):
+    """Many small proteins: lengths ~ N(500, 300) clipped to 50..3000, residues uniform over the 20
+    letters, every S / T residue a site (predict.py:631-636 picks sites by target residue), one ESM-2
+    table row per residue.  Returns device tensors in the layout dptm_score_proteins_device takes."""
+    rng = np.random.default_rng(seed)
+    lens = np.clip(np.rint(rng.normal(500, 300, n_proteins)), 50, 3000).astype(np.int64)
+    offs = np.zeros(n_proteins + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    total = int(offs[-1])
+    codes = rng.integers(0, 20, total, dtype=np.uint8)
+    is_site = (codes == 15) | (codes == 16)          # S, T
+    gidx = np.nonzero(is_site)[0]
+    if max_sites and len(gidx) > max_sites:
+        gidx = gidx[:max_sites]
+    prot = (np.searchsorted(offs, gidx, side="right") - 1).astype(np.int32)
+    pos = (gidx - offs[prot] + 1).astype(np.int32)   # 1-based, protein-local
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    n = len(gidx)
+    d = {"codes": torch.from_numpy(codes).to(dev), "seq_off": torch.from_numpy(offs).to(dev),
+         "esm_off": torch.from_numpy(offs.copy()).to(dev), "positions": torch.from_numpy(pos).to(dev),
+         "site_protein": torch.from_numpy(prot).to(dev), "esm": device_esm(total, g, dev),
+         "strct": device_struct(n, g, dev), "n": n, "proteins": n_proteins, "residues": total}
+    return d
+
+
+def measure_proteome(R: Ranks, sc, n_proteins: int, steps: int, warmup: int, seed: int = 4321) -> dict:
+    """All S/T sites of `n_proteins` synthetic proteins per step through ONE call of
+    dptm_score_proteins_device (windows assembled and ESM rows gathered on the device)."""
+    d = synthetic_proteome(n_proteins, seed + R.rank, R.dev)
+    n = d["n"]
+    out = torch.empty((n, 2), device=R.dev, dtype=torch.float32)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(_i):
+        sc.score_proteins_device(d["codes"].data_ptr(), d["seq_off"].data_ptr(), d["esm"].data_ptr(),
+                                 d["esm_off"].data_ptr(), d["proteins"], d["positions"].data_ptr(),
+                                 d["site_protein"].data_ptr(), d["strct"].data_ptr(), n, out.data_ptr(), stream)
+
+    elapsed = R.timed(step, steps, warmup)
+    total_sites = R.sum_over_ranks(float(n))
+    chk = out[:: max(1, n // 4096)].cpu().numpy()
+    assert np.isfinite(chk).all() and np.abs(chk.sum(axis=1) - 1).max() < 1e-5
+    sc.profile_begin()
+    step(0)
+    prof = sc.profile_end()
+    R.barrier()
+    a_ms, a_launches = prof["assemble"]
+    a_gbs = n * ASSEMBLE_BYTES_PER_SITE / (a_ms * 1e-3) / 1e9 if a_ms > 0 else 0.0
+    return {"proteins_per_gpu": n_proteins, "residues_per_gpu": d["residues"], "sites_per_gpu": n, "steps": steps,
+            "ms_per_step": elapsed / steps * 1e3, "sites_per_s": total_sites * steps / elapsed,
+            "proteins_per_s": R.world * n_proteins * steps / elapsed,
+            "assemble": {"ms_per_step": a_ms, "launches": a_launches, "bytes_per_site": ASSEMBLE_BYTES_PER_SITE,
+                         "gbs_algorithmic": a_gbs, "frac_of_hbm_peak": a_gbs / PEAK_HBM_GBS},
+            "kernel_ms_per_step": {k: round(v[0], 3) for k, v in prof.items()}}
+
+
+def proteome_main(args, R: Ranks) -> None:
+    from deepptmpred_amd import spec
+    from deepptmpred_amd.model import Model
+    model = Model(spec.synthetic_weights(7), device=R.local)
+    model.scorer.set_precision(args.precision)
+    m = measure_proteome(R, model.scorer, args.proteins, args.steps, args.warmup)
+    if R.rank == 0:
+        print(json.dumps({
+            "metric": "windows scored/sec (proteome: many proteins per call, device-side assembly)",
+            "value": m["sites_per_s"], "unit": "sites/s", "n_gpus": R.world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision,
+            "data": "synthetic proteins (lengths ~N(500,300), all S/T sites), seeded synthetic weights",
+            "config": {"workload": f"proteome: {args.proteins:,} synthetic proteins per GPU, every S/T site, "
+                                   f"{args.precision}, {R.world} x MI355X",
+                       "parallelism": f"dp{R.world} (proteins sharded, no collective)"},
+            "roofline": {"bound": "hbm", "kernel": "assemble_proteins_kernel",
+                         "achieved": m["assemble"]["gbs_algorithmic"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": m["assemble"]["frac_of_hbm_peak"], "traffic": None},
+            "proteome": m}))
+    R.finish()
+
+
+# ------------------------------------------------------------------------------------ headline
+
+def measure_streamed(model, n: int) -> dict:
+    """NumPy arrays in, NumPy array out through Model.predict (dptm_score): PCIe included."""
+    from deepptmpred_amd import spec
+    hx = spec.synthetic_inputs(n, 78)
+    model.predict([a[:4096] for a in hx])       # staging buffers, first launches
+    model.predict(hx)                            # pinned pipeline allocated
+    t1 = time.perf_counter()
+    p = model.predict(hx)
+    dt = time.perf_counter() - t1
+    assert p.shape == (n, 2) and np.isfinite(p).all()
+    return {"sites_per_s_one_gpu": n / dt, "sites": n, "input_gbs": n * BYTES_PER_SITE / dt / 1e9,
+            "note": "host arrays in, host arrays out (Model.predict): pinned double-buffered pipeline"}
 
 
 def main() -> None:
@@ -289,46 +486,35 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the short extra measurement of the other precision modes")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the streamed / proteome / sweep / train sub-blocks of the default line")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16x3", "f16", "bf16"],
                     help="arithmetic of the sequence-branch matrix products for the headline number")
     ap.add_argument("--train", action="store_true",
                     help="measure the training step (BASELINE config 5) instead of scoring")
     ap.add_argument("--batch", type=int, default=64, help="--train: sites per GPU per step")
+    ap.add_argument("--proteome", action="store_true",
+                    help="score many synthetic proteins per call with device-side window assembly instead")
+    ap.add_argument("--proteins", type=int, default=20000, help="--proteome: proteins per GPU per step")
     args = ap.parse_args()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)          # before anything touches a GPU
+    R = Ranks(args)
     if args.train:
-        return train_main(args)
+        return train_main(args, R)
     if args.types > 0:
-        return sweep_main(args)
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    dist = None
-    # rehearsal of the multi-rank path on a one-GPU box: DPTM_BENCH_REHEARSAL=1 puts every rank on GPU 0 and
-    # uses gloo for the barrier and the max-over-ranks reduction (RCCL refuses two ranks on one device)
-    rehearsal = os.environ.get("DPTM_BENCH_REHEARSAL") == "1"
-    if rehearsal:
-        local = 0
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device(f"cuda:{local}"))
-    torch.cuda.set_device(local)
-    dev = torch.device(f"cuda:{local}")
-    rdev = torch.device("cpu") if rehearsal else dev      # where the reduced scalar lives
+        return sweep_main(args, R)
+    if args.proteome:
+        return proteome_main(args, R)
+    rank, world, dev = R.rank, R.world, R.dev
 
     from deepptmpred_amd import spec
     from deepptmpred_amd.model import Model
 
     weights = spec.synthetic_weights(7)
-    model = Model(weights, device=local)
+    model = Model(weights, device=R.local)
     sc = model.scorer
     sc.set_precision(args.precision)
     n = args.sites
@@ -338,27 +524,10 @@ def main() -> None:
     stream = torch.cuda.current_stream().cuda_stream
     ptrs = [t.data_ptr() for t in x]
 
-    def step():
+    def step(_i=0):
         sc.score_device(ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], n, out.data_ptr(), stream)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=rdev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = R.timed(step, args.steps, args.warmup)
 
     # sanity: finite probabilities that sum to one
     chk = out[:: max(1, n // 4096)].cpu().numpy()
@@ -368,7 +537,7 @@ def main() -> None:
     sc.profile_begin()
     step()
     prof = sc.profile_end()
-    barrier()
+    R.barrier()
 
     # the other arithmetic modes on the same resident inputs (rank 0, two steps each): reported
     # beside the headline, never as `value`
@@ -394,7 +563,20 @@ def main() -> None:
             variants[mode] = {"sites_per_s_one_gpu": n / dt, "branch51_avg_launch_ms": v_ms / max(v_launches, 1),
                               "branch51_tflops_algorithmic": v_tf, "branch51_frac_of_mfma_peak": v_tf / PEAK_MFMA[mode]}
         sc.set_precision(args.precision)
-    barrier()
+    R.barrier()
+
+    # configs 4 and 5 and the host / proteome forms, on one GPU, beside the headline (never `value`)
+    extras = {}
+    if world == 1 and not args.no_extras:
+        extras["streamed_from_host"] = measure_streamed(model, min(n, 262144))
+        extras["proteome"] = measure_proteome(R, sc, 20000 if n >= 262144 else 200, 3, 1)
+        ns = min(n, 262144)
+        xs = [t[:ns] for t in x]
+        extras["sweep"] = measure_sweep(R, 17 if n >= 262144 else 3, ns, 2, 1, args.precision, xs)
+        del x, xs, out
+        torch.cuda.empty_cache()
+        extras["train"] = {"batch64": measure_train(R, 64, 50, 10),
+                           "batch8192": measure_train(R, 8192, 5, 2) if n >= 262144 else None}
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -404,6 +586,7 @@ def main() -> None:
         avg_s = b51_ms * 1e-3 / max(b51_launches, 1)
         achieved = sites_per_launch * FLOPS_BRANCH[51] / avg_s / 1e12 if avg_s > 0 else 0.0
         total_kernel_ms = sum(v[0] for v in prof.values())
+        traffic, traffic_file = measured_traffic(args.precision, sites_per_launch)
         line = {
             "metric": "windows scored/sec", "value": value, "unit": "sites/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
@@ -415,8 +598,8 @@ def main() -> None:
             "roofline": {"bound": "mfma", "kernel": KERNEL_NAME[args.precision], "achieved": achieved,
                          "peak": PEAK_MFMA[args.precision], "unit": "TFLOP/s",
                          "frac": achieved / PEAK_MFMA[args.precision],
-                         "traffic": measured_traffic(args.precision, sites_per_launch),
-                         "traffic_source": "profiles/r1_pmc_traffic.json (offline rocprofv3 --pmc passes of this command)",
+                         "traffic": traffic,
+                         "traffic_source": f"{traffic_file} (offline rocprofv3 --pmc passes of this command)" if traffic_file else None,
                          "avg_launch_ms": avg_s * 1e3, "sites_per_launch": sites_per_launch,
                          "flops_per_site": FLOPS_BRANCH[51]},
             "whole_path": {"tflops": value / world * FLOPS_PER_SITE / 1e12,
@@ -428,12 +611,11 @@ def main() -> None:
         }
         if variants:
             line["variants"] = variants
+        line.update(extras)
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N = 1 only
             line["cpu_baseline"] = cpu_baseline(weights)
         print(json.dumps(line))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    R.finish()
 
 
 if __name__ == "__main__":

@@ -26,6 +26,7 @@ PRECISIONS = {"f32": 0, "bf16": 1, "f16": 2, "f16x3": 3}
 EXPORTS = (
     "dptm_weight_count", "dptm_create", "dptm_destroy", "dptm_score", "dptm_score_protein",
     "dptm_score_device", "dptm_score_protein_device", "dptm_assemble_device", "dptm_sync",
+    "dptm_score_proteins", "dptm_score_proteins_device", "dptm_assemble_proteins_device",
     "dptm_profile_begin", "dptm_profile_end", "dptm_chunk_sites", "dptm_last_error",
     "dptm_set_precision", "dptm_trainer_create", "dptm_trainer_destroy", "dptm_trainer_forward_backward",
     "dptm_trainer_grad_buffer", "dptm_trainer_param_floats", "dptm_trainer_apply",
@@ -129,6 +130,12 @@ def load_library() -> C.CDLL:
     lib.dptm_score_protein_device.argtypes = [vp, u8p, i64, f32p, i64, i32p, f32p, i64, f32p, vp]
     lib.dptm_assemble_device.restype = C.c_int
     lib.dptm_assemble_device.argtypes = [vp, u8p, i64, i64, i32p, i64, u8p, u8p, u8p, i32p, vp]
+    lib.dptm_score_proteins.restype = C.c_int
+    lib.dptm_score_proteins.argtypes = [vp, u8p, vp, f32p, vp, i64, i32p, i32p, f32p, i64, f32p]
+    lib.dptm_score_proteins_device.restype = C.c_int
+    lib.dptm_score_proteins_device.argtypes = [vp, u8p, vp, f32p, vp, i64, i32p, i32p, f32p, i64, f32p, vp]
+    lib.dptm_assemble_proteins_device.restype = C.c_int
+    lib.dptm_assemble_proteins_device.argtypes = [vp, u8p, vp, vp, i32p, i32p, i64, u8p, u8p, u8p, i32p, vp]
     lib.dptm_sync.restype = C.c_int
     lib.dptm_sync.argtypes = [vp]
     lib.dptm_profile_begin.restype = C.c_int
@@ -269,7 +276,42 @@ class Scorer:
         _check(self._lib, rc, "dptm_score_protein")
         return out
 
+    def score_proteins(self, codes, seq_offsets, esm_tables, esm_offsets, positions, site_protein, strct) -> np.ndarray:
+        """Sites of many proteins in one call (``dptm_score_proteins``); see include/dptm.h for the layout."""
+        n = len(positions)
+        n_prot = len(seq_offsets) - 1
+        _buffer(codes, np.uint8, (None,), "dptm_score_proteins: codes")
+        _buffer(seq_offsets, np.int64, (n_prot + 1,), "dptm_score_proteins: seq_offsets")
+        _buffer(esm_offsets, np.int64, (n_prot + 1,), "dptm_score_proteins: esm_offsets")
+        _buffer(positions, np.int32, (n,), "dptm_score_proteins: positions")
+        _buffer(site_protein, np.int32, (n,), "dptm_score_proteins: site_protein")
+        _buffer(strct, np.float32, (n, self.spec.struct_feature_dim), "dptm_score_proteins: struct")
+        if n_prot < 0 or (n_prot >= 0 and len(codes) != int(seq_offsets[-1])):
+            raise ValueError("dptm_score_proteins: seq_offsets[-1] must equal len(codes)")
+        rows = int(esm_offsets[-1])
+        tp = C.c_void_p(None)
+        if rows:
+            _buffer(esm_tables, np.float32, (rows, self.spec.esm_dim), "dptm_score_proteins: esm tables")
+            tp = _ptr(esm_tables)
+        out = np.empty((n, 2), dtype=np.float32)
+        rc = self._lib.dptm_score_proteins(self._h, _ptr(codes), _ptr(seq_offsets), tp, _ptr(esm_offsets), n_prot,
+                                           _ptr(positions), _ptr(site_protein), _ptr(strct), n, _ptr(out))
+        _check(self._lib, rc, "dptm_score_proteins")
+        return out
+
     # ---- device-pointer calls (integers = device addresses, e.g. torch data_ptr())
+    def score_proteins_device(self, codes, seq_offsets, esm_tables, esm_offsets, n_proteins, positions, site_protein,
+                              strct, n, out, stream=0) -> None:
+        rc = self._lib.dptm_score_proteins_device(self._h, codes, seq_offsets, esm_tables or None, esm_offsets, n_proteins,
+                                                  positions, site_protein, strct, n, out, C.c_void_p(stream or None))
+        _check(self._lib, rc, "dptm_score_proteins_device")
+
+    def assemble_proteins_device(self, codes, seq_offsets, esm_offsets, positions, site_protein, n, tok21, tok33, tok51,
+                                 esm_row, stream=0) -> None:
+        rc = self._lib.dptm_assemble_proteins_device(self._h, codes, seq_offsets, esm_offsets, positions, site_protein, n,
+                                                     tok21, tok33, tok51, esm_row, C.c_void_p(stream or None))
+        _check(self._lib, rc, "dptm_assemble_proteins_device")
+
     def score_device(self, tok21, tok33, tok51, strct, esm, n, out, stream=0) -> None:
         rc = self._lib.dptm_score_device(self._h, tok21, tok33, tok51, strct, esm, n, out,
                                          C.c_void_p(stream or None))

@@ -3,6 +3,8 @@
 // dptm_kernels.hip.  Host code only; no kernel lives in this file.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -159,6 +161,15 @@ struct ProfRec {
     hipEvent_t a, b;
 };
 
+// per-pass activations of the per-site layers: concat [m][576], h1 [m][512], t1 [m][512], t2 [m][256]
+struct Workspace {
+    float* concat = nullptr;
+    float* h1 = nullptr;
+    float* t1 = nullptr;
+    float* t2 = nullptr;
+};
+constexpr int64_t kWorkspaceFloatsPerSite = kConcat + kEsm1 + kT1 + kT2;   // 1856
+
 }  // namespace
 
 struct dptm_handle {
@@ -172,11 +183,8 @@ struct dptm_handle {
     std::vector<float> blob;              // canonical weights, kept to build the half-precision images on demand
     bool half_ready = false;
     DenseLayer strct, esm1, esm2, t1, t2, head;
-    // per-chunk workspace
-    float* d_concat = nullptr;
-    float* d_h1 = nullptr;
-    float* d_t1 = nullptr;
-    float* d_t2 = nullptr;
+    Workspace ws;                         // per-chunk workspace (kChunkSites rows)
+    bool plain = false;                   // set for the duration of a call that may create no stream or event
     float* d_zero_row = nullptr;
     // per-chunk staging for assembled windows
     uint8_t* d_tok[3] = {nullptr, nullptr, nullptr};
@@ -191,6 +199,13 @@ struct dptm_handle {
     float* s_table = nullptr;
     int64_t s_table_cap = 0;
     int32_t* s_pos = nullptr;
+    // whole-call staging of the multi-protein host entry point (grow-only)
+    int64_t* s_seq_off = nullptr;
+    int64_t* s_esm_off = nullptr;
+    int64_t s_seq_off_cap = 0, s_esm_off_cap = 0;
+    int32_t* s_site_pos = nullptr;
+    int32_t* s_site_prot = nullptr;
+    int64_t s_site_pos_cap = 0, s_site_prot_cap = 0;
     // second staging slot, copy stream and events of the pipelined host-buffer entry point (dptm_score)
     float* s2_strct = nullptr;
     float* s2_esm = nullptr;
@@ -359,7 +374,7 @@ struct Prof {
     int cls;
     bool on;
     hipEvent_t a = nullptr, b = nullptr;
-    Prof(dptm_handle* h_, hipStream_t st_, int cls_) : h(h_), st(st_), cls(cls_), on(h_->prof_armed) {
+    Prof(dptm_handle* h_, hipStream_t st_, int cls_) : h(h_), st(st_), cls(cls_), on(h_->prof_armed && !h_->plain) {
         if (on) {
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
             (void)hipEventRecord(a, st);
@@ -400,11 +415,11 @@ int run_dense(dptm_handle* h, const DenseLayer& L, int epi, const float* x, int6
 }
 
 // One chunk (m <= kChunkSites) of the forward pass, everything device-resident.
-int score_chunk(dptm_handle* h, const uint8_t* const tok[3], const float* strct, const float* esm,
+int score_chunk(dptm_handle* h, const Workspace& ws, const uint8_t* const tok[3], const float* strct, const float* esm,
                 int64_t esm_ld, const int32_t* esm_row, int64_t m, float* out, hipStream_t st) {
     // A small call cannot fill the chip with any one kernel, so its three sequence branches run on side
     // streams next to the structure / ESM layers; a large call keeps everything on one stream.
-    const bool fan_out = m <= kDenseSmallRows && !h->prof_armed;
+    const bool fan_out = m <= kDenseSmallRows && !h->prof_armed && !h->plain;
     if (fan_out && !h->ev_fork) {
         for (int b = 0; b < 3; ++b) {
             HIP_TRY(hipStreamCreateWithFlags(&h->aux[b], hipStreamNonBlocking));
@@ -421,33 +436,33 @@ int score_chunk(dptm_handle* h, const uint8_t* const tok[3], const float* strct,
         }
         Prof p(h, bs, DPTM_PROF_BRANCH21 + b);
         if (h->precision == kModeF32) {
-            HIP_TRY(launch_branch(kWin[b], h->d_branch[b], tok[b], m, h->d_concat, kConcat, b * kD, bs));
+            HIP_TRY(launch_branch(kWin[b], h->d_branch[b], tok[b], m, ws.concat, kConcat, b * kD, bs));
         } else {
             const uint16_t* hi = h->d_branch_half[b][h->precision == kModeBF16 ? 0 : 1];
             HIP_TRY(launch_branch_h(h->precision, kWin[b], h->d_branch[b], hi, h->d_branch_half[b][2], tok[b], m,
-                                    h->d_concat, kConcat, b * kD, bs));
+                                    ws.concat, kConcat, b * kD, bs));
         }
         if (fan_out) HIP_TRY(hipEventRecord(h->ev_join[b], bs));
     }
     int rc;
-    if ((rc = run_dense(h, h->strct, kEpiSwishAffine, strct, kStruct, nullptr, m, h->d_concat, kConcat,
+    if ((rc = run_dense(h, h->strct, kEpiSwishAffine, strct, kStruct, nullptr, m, ws.concat, kConcat,
                         3 * kD, st, DPTM_PROF_STRUCT)))
         return rc;
-    if ((rc = run_dense(h, h->esm1, kEpiSwishAffine, esm, esm_ld, esm_row, m, h->d_h1, kEsm1, 0, st,
+    if ((rc = run_dense(h, h->esm1, kEpiSwishAffine, esm, esm_ld, esm_row, m, ws.h1, kEsm1, 0, st,
                         DPTM_PROF_ESM1)))
         return rc;
-    if ((rc = run_dense(h, h->esm2, kEpiSwish, h->d_h1, kEsm1, nullptr, m, h->d_concat, kConcat,
+    if ((rc = run_dense(h, h->esm2, kEpiSwish, ws.h1, kEsm1, nullptr, m, ws.concat, kConcat,
                         3 * kD + kStructUnits, st, DPTM_PROF_ESM2)))
         return rc;
     if (fan_out)
         for (int b = 0; b < 3; ++b) HIP_TRY(hipStreamWaitEvent(st, h->ev_join[b], 0));
-    if ((rc = run_dense(h, h->t1, kEpiSwishAffine, h->d_concat, kConcat, nullptr, m, h->d_t1, kT1, 0, st,
+    if ((rc = run_dense(h, h->t1, kEpiSwishAffine, ws.concat, kConcat, nullptr, m, ws.t1, kT1, 0, st,
                         DPTM_PROF_TRUNK1)))
         return rc;
-    if ((rc = run_dense(h, h->t2, kEpiSwishAffine, h->d_t1, kT1, nullptr, m, h->d_t2, kT2, 0, st,
+    if ((rc = run_dense(h, h->t2, kEpiSwishAffine, ws.t1, kT1, nullptr, m, ws.t2, kT2, 0, st,
                         DPTM_PROF_TRUNK2)))
         return rc;
-    return run_dense(h, h->head, kEpiHead, h->d_t2, kT2, nullptr, m, out, 2, 0, st, DPTM_PROF_HEAD);
+    return run_dense(h, h->head, kEpiHead, ws.t2, kT2, nullptr, m, out, 2, 0, st, DPTM_PROF_HEAD);
 }
 
 int ensure_host_staging(dptm_handle* h) {
@@ -557,6 +572,86 @@ struct DrainOnError {
     }
 };
 
+// rows of the concatenated ESM tables that the sites [i0, i1) need, gathered into dst [i1-i0][1280]
+// (zero row when the protein has no table or the position lies beyond it: predict.py:493,498-500)
+void gather_esm_rows(float* dst, const float* tables, const int64_t* esm_off, const int32_t* positions,
+                     const int32_t* site_protein, int64_t i0, int64_t i1) {
+    auto work = [=](int64_t a, int64_t b) {
+        for (int64_t i = a; i < b; ++i) {
+            const int64_t p = site_protein[i], r = (int64_t)positions[i] - 1;
+            float* d = dst + (i - i0) * (int64_t)kEsm;
+            if (tables && r < esm_off[p + 1] - esm_off[p])
+                std::memcpy(d, tables + (esm_off[p] + r) * (int64_t)kEsm, kEsm * sizeof(float));
+            else
+                std::memset(d, 0, kEsm * sizeof(float));
+        }
+    };
+    const int64_t m = i1 - i0;
+    unsigned hw = std::thread::hardware_concurrency();
+    int64_t nt = std::min<int64_t>(std::min<unsigned>(hw ? hw : 1u, 6u), m / 2048);
+    if (nt <= 1) {
+        work(i0, i1);
+        return;
+    }
+    std::vector<std::thread> pool;
+    pool.reserve(nt);
+    const int64_t per = (m + nt - 1) / nt;
+    int64_t done = i0 + per;      // the first slice runs on this thread
+    for (int64_t t = 1; t < nt && done < i1; ++t) {
+        const int64_t a = done, b = std::min(i1, a + per);
+        try {
+            pool.emplace_back(work, a, b);
+        } catch (...) {
+            work(a, i1);
+            done = i1;
+            break;
+        }
+        done = b;
+    }
+    work(i0, std::min(i1, i0 + per));
+    for (auto& th : pool) th.join();
+}
+
+// grow-only device buffer
+template <typename T>
+int ensure_capacity(T** buf, int64_t* cap, int64_t want) {
+    if (want <= *cap) return DPTM_OK;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *cap = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(buf), (size_t)want * sizeof(T)));
+    *cap = want;
+    return DPTM_OK;
+}
+
+int check_protein_tables(const char* who, const int64_t* seq_off, const int64_t* esm_off, int64_t n_proteins,
+                         const int32_t* positions, const int32_t* site_protein, int64_t n) {
+    char msg[192];
+    if (seq_off[0] != 0 || esm_off[0] != 0) return fail(DPTM_EINVAL, std::string(who) + ": offsets must start at 0");
+    for (int64_t p = 0; p < n_proteins; ++p)
+        if (seq_off[p + 1] < seq_off[p] || esm_off[p + 1] < esm_off[p]) {
+            std::snprintf(msg, sizeof msg, "%s: offsets decrease at protein %lld", who, (long long)p);
+            return fail(DPTM_EINVAL, msg);
+        }
+    if (esm_off[n_proteins] > INT32_MAX)
+        return fail(DPTM_EINVAL, std::string(who) + ": more than 2^31-1 ESM table rows in one call");
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t p = site_protein[i];
+        if (p < 0 || p >= n_proteins) {
+            std::snprintf(msg, sizeof msg, "%s: site %lld names protein %lld of %lld", who, (long long)i, (long long)p,
+                          (long long)n_proteins);
+            return fail(DPTM_EINVAL, msg);
+        }
+        const int64_t L = seq_off[p + 1] - seq_off[p];
+        if (positions[i] < 1 || positions[i] > L) {
+            std::snprintf(msg, sizeof msg, "%s: position %d (site %lld, protein %lld) outside 1..%lld", who, positions[i],
+                          (long long)i, (long long)p, (long long)L);
+            return fail(DPTM_EINVAL, msg);
+        }
+    }
+    return DPTM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -608,8 +703,9 @@ void dptm_destroy(dptm_handle* h) {
     free_dense(h->t1);
     free_dense(h->t2);
     free_dense(h->head);
-    void* bufs[] = {h->d_concat, h->d_h1, h->d_t1, h->d_t2, h->d_zero_row, h->d_esm_row, h->s_strct,
-                    h->s_esm, h->s_out, h->s_codes, h->s_table, h->s_pos, h->s2_strct, h->s2_esm, h->s2_out};
+    void* bufs[] = {h->ws.concat, h->ws.h1, h->ws.t1, h->ws.t2, h->d_zero_row, h->d_esm_row, h->s_strct,
+                    h->s_esm, h->s_out, h->s_codes, h->s_table, h->s_pos, h->s2_strct, h->s2_esm, h->s2_out,
+                    h->s_seq_off, h->s_esm_off, h->s_site_pos, h->s_site_prot};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -670,10 +766,12 @@ int dptm_create(const void* weights, size_t nbytes, const dptm_spec* spec, int d
         if (hipMalloc(p, bytes) != hipSuccess) return fail(DPTM_ENOMEM, "dptm_create: device allocation failed");
         return DPTM_OK;
     };
-    if ((rc = dalloc((void**)&h->d_concat, kChunkSites * (size_t)kConcat * 4))) return bail(rc);
-    if ((rc = dalloc((void**)&h->d_h1, kChunkSites * (size_t)kEsm1 * 4))) return bail(rc);
-    if ((rc = dalloc((void**)&h->d_t1, kChunkSites * (size_t)kT1 * 4))) return bail(rc);
-    if ((rc = dalloc((void**)&h->d_t2, kChunkSites * (size_t)kT2 * 4))) return bail(rc);
+    if ((rc = dalloc((void**)&h->ws.concat, kChunkSites * (size_t)kConcat * 4))) return bail(rc);
+    if ((rc = dalloc((void**)&h->ws.h1, kChunkSites * (size_t)kEsm1 * 4))) return bail(rc);
+    if ((rc = dalloc((void**)&h->ws.t1, kChunkSites * (size_t)kT1 * 4))) return bail(rc);
+    if ((rc = dalloc((void**)&h->ws.t2, kChunkSites * (size_t)kT2 * 4))) return bail(rc);
+    if (hipError_t e = prepare_kernels(); e != hipSuccess)
+        return bail(fail(DPTM_EHIP, std::string("dptm_create: kernel set-up failed: ") + hipGetErrorString(e)));
     if ((rc = dalloc((void**)&h->d_zero_row, kEsm * 4))) return bail(rc);
     if (hipMemset(h->d_zero_row, 0, kEsm * 4) != hipSuccess) return bail(fail(DPTM_EHIP, "hipMemset failed"));
     for (int b = 0; b < 3; ++b)
@@ -726,7 +824,7 @@ int dptm_score_device(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33
     for (int64_t c0 = 0; c0 < n; c0 += kChunkSites) {
         const int64_t m = n - c0 < kChunkSites ? n - c0 : kChunkSites;
         const uint8_t* tok[3] = {tok21 + c0 * 21, tok33 + c0 * 33, tok51 + c0 * 51};
-        int rc = score_chunk(h, tok, strct + c0 * kStruct, esm + c0 * (int64_t)kEsm, kEsm, nullptr, m,
+        int rc = score_chunk(h, h->ws, tok, strct + c0 * kStruct, esm + c0 * (int64_t)kEsm, kEsm, nullptr, m,
                              out + c0 * 2, st);
         if (rc) return rc;
     }
@@ -745,8 +843,18 @@ int dptm_assemble_device(dptm_handle* h, const uint8_t* codes, int64_t L, int64_
         return fail(DPTM_EINVAL, "dptm_assemble_device: NULL buffer");
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    AssembleArgs a{};
+    a.codes = codes;
+    a.L = L;
+    a.esm_rows = esm_rows;
+    a.positions = positions;
+    a.n = n;
+    a.t21 = tok21;
+    a.t33 = tok33;
+    a.t51 = tok51;
+    a.esm_row = esm_row;
     Prof p(h, st, DPTM_PROF_ASSEMBLE);
-    HIP_TRY(launch_assemble(codes, L, esm_rows, positions, n, tok21, tok33, tok51, esm_row, st));
+    HIP_TRY(launch_assemble(a, st));
     return DPTM_OK;
 } catch (...) {
     return on_exception("dptm_assemble_device");
@@ -771,7 +879,7 @@ int dptm_score_protein_device(dptm_handle* h, const uint8_t* codes, int64_t L, c
                                       h->d_tok[2], h->d_esm_row, st);
         if (rc) return rc;
         const uint8_t* tok[3] = {h->d_tok[0], h->d_tok[1], h->d_tok[2]};
-        rc = score_chunk(h, tok, strct + c0 * kStruct, table, kEsm, h->d_esm_row, m, out + c0 * 2, st);
+        rc = score_chunk(h, h->ws, tok, strct + c0 * kStruct, table, kEsm, h->d_esm_row, m, out + c0 * 2, st);
         if (rc) return rc;
     }
     return DPTM_OK;
@@ -797,7 +905,7 @@ int dptm_score(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const
         HIP_TRY(hipMemcpyAsync(h->s_strct, strct, n * kStruct * sizeof(float), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipMemcpyAsync(h->s_esm, esm, n * (size_t)kEsm * sizeof(float), hipMemcpyHostToDevice, h->stream));
         const uint8_t* tok[3] = {h->s_tok[0], h->s_tok[1], h->s_tok[2]};
-        if ((rc = score_chunk(h, tok, h->s_strct, h->s_esm, kEsm, nullptr, n, h->s_out, h->stream))) return rc;
+        if ((rc = score_chunk(h, h->ws, tok, h->s_strct, h->s_esm, kEsm, nullptr, n, h->s_out, h->stream))) return rc;
         HIP_TRY(hipMemcpyAsync(out, h->s_out, n * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         drain.armed = false;
@@ -836,7 +944,7 @@ int dptm_score(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const
         HIP_TRY(hipEventRecord(h->ev_copied[slot], h->copy_stream));
         HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_copied[slot], 0));
         const uint8_t* tok[3] = {s_tok[slot][0], s_tok[slot][1], s_tok[slot][2]};
-        rc = score_chunk(h, tok, s_strct[slot], s_esm[slot], kEsm, nullptr, m, s_out[slot], h->stream);
+        rc = score_chunk(h, h->ws, tok, s_strct[slot], s_esm[slot], kEsm, nullptr, m, s_out[slot], h->stream);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(h->pin_out[slot], s_out[slot], m * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipEventRecord(h->ev_scored[slot], h->stream));
@@ -901,6 +1009,154 @@ int dptm_score_protein(dptm_handle* h, const uint8_t* codes, int64_t L, const fl
     return DPTM_OK;
 } catch (...) {
     return on_exception("dptm_score_protein");
+}
+
+int dptm_assemble_proteins_device(dptm_handle* h, const uint8_t* codes, const int64_t* seq_offsets,
+                                  const int64_t* esm_offsets, const int32_t* positions, const int32_t* site_protein,
+                                  int64_t n, uint8_t* tok21, uint8_t* tok33, uint8_t* tok51, int32_t* esm_row,
+                                  void* stream) try {
+    if (!h) return fail(DPTM_EINVAL, "dptm_assemble_proteins_device: NULL handle");
+    if (n < 0) return fail(DPTM_EINVAL, "dptm_assemble_proteins_device: n < 0");
+    if (n == 0) return DPTM_OK;
+    if (!codes || !seq_offsets || !esm_offsets || !positions || !site_protein || !tok21 || !tok33 || !tok51 || !esm_row)
+        return fail(DPTM_EINVAL, "dptm_assemble_proteins_device: NULL buffer");
+    if (misaligned(seq_offsets, 8) || misaligned(esm_offsets, 8) || misaligned(positions, 4) || misaligned(site_protein, 4) ||
+        misaligned(esm_row, 4))
+        return fail(DPTM_EINVAL, "dptm_assemble_proteins_device: offsets must be 8-byte aligned, positions / site_protein / esm_row 4-byte");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    AssembleArgs a{};
+    a.codes = codes;
+    a.seq_off = seq_offsets;
+    a.esm_off = esm_offsets;
+    a.site_protein = site_protein;
+    a.positions = positions;
+    a.n = n;
+    a.t21 = tok21;
+    a.t33 = tok33;
+    a.t51 = tok51;
+    a.esm_row = esm_row;
+    Prof p(h, st, DPTM_PROF_ASSEMBLE);
+    HIP_TRY(launch_assemble(a, st));
+    return DPTM_OK;
+} catch (...) {
+    return on_exception("dptm_assemble_proteins_device");
+}
+
+int dptm_score_proteins_device(dptm_handle* h, const uint8_t* codes, const int64_t* seq_offsets,
+                               const float* esm_tables, const int64_t* esm_offsets, int64_t n_proteins,
+                               const int32_t* positions, const int32_t* site_protein, const float* strct, int64_t n,
+                               float* out, void* stream) try {
+    if (!h) return fail(DPTM_EINVAL, "dptm_score_proteins_device: NULL handle");
+    if (n < 0 || n_proteins < 0) return fail(DPTM_EINVAL, "dptm_score_proteins_device: negative size");
+    if (n == 0) return DPTM_OK;
+    if (n_proteins == 0) return fail(DPTM_EINVAL, "dptm_score_proteins_device: sites but no proteins");
+    if (!codes || !seq_offsets || !esm_offsets || !positions || !site_protein || !strct || !out)
+        return fail(DPTM_EINVAL, "dptm_score_proteins_device: NULL buffer");
+    if (misaligned(strct, 16) || (esm_tables && misaligned(esm_tables, 16)) || misaligned(out, 8))
+        return fail(DPTM_EINVAL, "dptm_score_proteins_device: struct / esm tables must be 16-byte aligned, out 8-byte");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    // esm_tables == NULL: the caller states that no protein has a table (all esm_offsets equal), so no row is read
+    const float* table = esm_tables ? esm_tables : h->d_zero_row;
+    for (int64_t c0 = 0; c0 < n; c0 += kChunkSites) {
+        const int64_t m = n - c0 < kChunkSites ? n - c0 : kChunkSites;
+        int rc = dptm_assemble_proteins_device(h, codes, seq_offsets, esm_offsets, positions + c0, site_protein + c0, m,
+                                               h->d_tok[0], h->d_tok[1], h->d_tok[2], h->d_esm_row, st);
+        if (rc) return rc;
+        const uint8_t* tok[3] = {h->d_tok[0], h->d_tok[1], h->d_tok[2]};
+        rc = score_chunk(h, h->ws, tok, strct + c0 * kStruct, table, kEsm, h->d_esm_row, m, out + c0 * 2, st);
+        if (rc) return rc;
+    }
+    return DPTM_OK;
+} catch (...) {
+    return on_exception("dptm_score_proteins_device");
+}
+
+int dptm_score_proteins(dptm_handle* h, const uint8_t* codes, const int64_t* seq_offsets, const float* esm_tables,
+                        const int64_t* esm_offsets, int64_t n_proteins, const int32_t* positions,
+                        const int32_t* site_protein, const float* strct, int64_t n, float* out) try {
+    if (!h) return fail(DPTM_EINVAL, "dptm_score_proteins: NULL handle");
+    if (n < 0 || n_proteins < 0) return fail(DPTM_EINVAL, "dptm_score_proteins: negative size");
+    if (n == 0) return DPTM_OK;
+    if (n_proteins == 0) return fail(DPTM_EINVAL, "dptm_score_proteins: sites but no proteins");
+    if (!codes || !seq_offsets || !esm_offsets || !positions || !site_protein || !strct || !out)
+        return fail(DPTM_EINVAL, "dptm_score_proteins: NULL buffer");
+    int rc = check_protein_tables("dptm_score_proteins", seq_offsets, esm_offsets, n_proteins, positions, site_protein, n);
+    if (rc) return rc;
+    if (!esm_tables && esm_offsets[n_proteins] != 0)
+        return fail(DPTM_EINVAL, "dptm_score_proteins: esm_offsets name table rows but esm_tables is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    if ((rc = ensure_host_staging(h))) return rc;
+    const int64_t residues = seq_offsets[n_proteins];
+    if ((rc = ensure_capacity(&h->s_codes, &h->s_codes_cap, std::max<int64_t>(residues, 1)))) return rc;
+    if ((rc = ensure_capacity(&h->s_seq_off, &h->s_seq_off_cap, n_proteins + 1))) return rc;
+    if ((rc = ensure_capacity(&h->s_esm_off, &h->s_esm_off_cap, n_proteins + 1))) return rc;
+    if ((rc = ensure_capacity(&h->s_site_pos, &h->s_site_pos_cap, n))) return rc;
+    if ((rc = ensure_capacity(&h->s_site_prot, &h->s_site_prot_cap, n))) return rc;
+    DrainOnError drain{h};
+    // Everything but the ESM rows is small and goes up whole: residue codes (1 B per residue), offsets, positions.
+    // ESM rows cross PCIe gathered -- one 5 KB row per SITE, not per residue -- and the windows are assembled on the device.
+    HIP_TRY(hipMemcpyAsync(h->s_codes, codes, (size_t)residues, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->s_seq_off, seq_offsets, (size_t)(n_proteins + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->s_esm_off, esm_offsets, (size_t)(n_proteins + 1) * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->s_site_pos, positions, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->s_site_prot, site_protein, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    auto assemble = [&](int64_t c0, int64_t m) {
+        return dptm_assemble_proteins_device(h, h->s_codes, h->s_seq_off, h->s_esm_off, h->s_site_pos + c0,
+                                             h->s_site_prot + c0, m, h->d_tok[0], h->d_tok[1], h->d_tok[2], h->d_esm_row,
+                                             h->stream);
+    };
+    const uint8_t* tok[3] = {h->d_tok[0], h->d_tok[1], h->d_tok[2]};
+    if (n <= kChunkSites) {
+        std::vector<float> rows((size_t)n * kEsm);
+        gather_esm_rows(rows.data(), esm_tables, esm_offsets, positions, site_protein, 0, n);
+        HIP_TRY(hipMemcpyAsync(h->s_esm, rows.data(), rows.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->s_strct, strct, (size_t)n * kStruct * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        if ((rc = assemble(0, n))) return rc;
+        if ((rc = score_chunk(h, h->ws, tok, h->s_strct, h->s_esm, kEsm, nullptr, n, h->s_out, h->stream))) return rc;
+        HIP_TRY(hipMemcpyAsync(out, h->s_out, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        drain.armed = false;
+        return DPTM_OK;
+    }
+    if ((rc = ensure_pipeline(h))) return rc;
+    // the two-slot pipeline of dptm_score: gather of chunk i+1 into pinned memory and its transfer overlap the
+    // scoring of chunk i (the token windows of a chunk are produced on the scoring stream, in order)
+    float* const s_strct[2] = {h->s_strct, h->s2_strct};
+    float* const s_esm[2] = {h->s_esm, h->s2_esm};
+    float* const s_out[2] = {h->s_out, h->s2_out};
+    auto retire = [&](int slot, int64_t c0, int64_t m) -> int {
+        HIP_TRY(hipEventSynchronize(h->ev_scored[slot]));
+        std::memcpy(out + c0 * 2, h->pin_out[slot], (size_t)m * 2 * sizeof(float));
+        return DPTM_OK;
+    };
+    int64_t prev_c0 = 0, prev_m = 0, i = 0;
+    for (int64_t c0 = 0; c0 < n; c0 += kChunkSites, ++i) {
+        const int64_t m = n - c0 < kChunkSites ? n - c0 : kChunkSites;
+        const int slot = (int)(i & 1);
+        uint8_t* pin = h->pin_in[slot];
+        if (i >= 2) HIP_TRY(hipEventSynchronize(h->ev_copied[slot]));   // the pinned block has crossed PCIe
+        gather_esm_rows(reinterpret_cast<float*>(pin + kPinEsm), esm_tables, esm_offsets, positions, site_protein, c0, c0 + m);
+        std::memcpy(pin + kPinStruct, strct + c0 * kStruct, (size_t)m * kStruct * sizeof(float));
+        if (i >= 2) HIP_TRY(hipStreamWaitEvent(h->copy_stream, h->ev_scored[slot], 0));   // device slot free again
+        HIP_TRY(hipMemcpyAsync(s_esm[slot], pin + kPinEsm, (size_t)m * kEsm * sizeof(float), hipMemcpyHostToDevice, h->copy_stream));
+        HIP_TRY(hipMemcpyAsync(s_strct[slot], pin + kPinStruct, (size_t)m * kStruct * sizeof(float), hipMemcpyHostToDevice, h->copy_stream));
+        HIP_TRY(hipEventRecord(h->ev_copied[slot], h->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_copied[slot], 0));
+        if ((rc = assemble(c0, m))) return rc;
+        if ((rc = score_chunk(h, h->ws, tok, s_strct[slot], s_esm[slot], kEsm, nullptr, m, s_out[slot], h->stream))) return rc;
+        HIP_TRY(hipMemcpyAsync(h->pin_out[slot], s_out[slot], (size_t)m * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipEventRecord(h->ev_scored[slot], h->stream));
+        if (i >= 1 && (rc = retire(slot ^ 1, prev_c0, prev_m))) return rc;
+        prev_c0 = c0;
+        prev_m = m;
+    }
+    if ((rc = retire((int)((i - 1) & 1), prev_c0, prev_m))) return rc;
+    drain.armed = false;
+    return DPTM_OK;
+} catch (...) {
+    return on_exception("dptm_score_proteins");
 }
 
 int dptm_profile_begin(dptm_handle* h) try {

@@ -40,8 +40,24 @@ hipError_t launch_branch_h(int mode, int w, const float* params, const void* whi
 hipError_t launch_dense(const DenseArgs& a, int epi, hipStream_t st);
 // half-precision-MFMA dense layer (swish epilogues only; k a multiple of 16): whi/wlo = packed half images of a.w
 hipError_t launch_dense_h(int mode, const DenseArgs& a, int epi, const void* whi, const void* wlo, hipStream_t st);
-hipError_t launch_assemble(const uint8_t* codes, int64_t L, int64_t esm_rows,
-                           const int32_t* positions, int64_t n, uint8_t* t21, uint8_t* t33,
-                           uint8_t* t51, int32_t* esm_row, hipStream_t st);
+// Window assembly for n sites (see assemble_kernel).  seq_off / esm_off / site_protein are nullptr for the
+// one-protein form, which takes L and esm_rows instead.
+struct AssembleArgs {
+    const uint8_t* codes;          // residue codes, all proteins concatenated
+    const int64_t* seq_off;        // [P+1] first residue of each protein in codes
+    const int64_t* esm_off;        // [P+1] first ESM table row of each protein (equal neighbours: no table)
+    const int32_t* site_protein;   // [n] protein of each site
+    int64_t L;                     // one-protein form: sequence length
+    int64_t esm_rows;              // one-protein form: table rows
+    const int32_t* positions;      // [n] 1-based, protein-local, already validated
+    int64_t n;
+    uint8_t* t21;                  // [n][21]
+    uint8_t* t33;                  // [n][33]
+    uint8_t* t51;                  // [n][51]
+    int32_t* esm_row;              // [n] table row of the site, or -1 (zero row)
+    bool words;                    // set by launch_assemble
+};
+hipError_t launch_assemble(const AssembleArgs& a, hipStream_t st);
+hipError_t prepare_kernels();
 
 }  // namespace dptm

@@ -770,42 +770,81 @@ __global__ __launch_bounds__(512) void dense_small_kernel(DenseArgs p) {
 }
 
 // ------------------------------------------------------------------------------------
-// Window assembly (predict.py:529-560): column c of the window of 1-based position
-// `pos` is sequence index pos-1-half+c, or the padding code 20 outside 0..L-1.
-// One thread per output byte of the widest layout; rows are contiguous so the byte
-// stores of a wavefront coalesce.
+// Window assembly (predict.py:529-560) and the ESM row index (predict.py:487-501) for sites of many
+// proteins at once: column c of the W-window of 1-based, protein-local position `pos` is residue
+// pos-1-(W-1)/2+c of that protein, or the padding code 20 outside 0..L-1 (also for codes > 20).
+// A workgroup owns 256 consecutive sites: their (sequence base, length, position) go to LDS once,
+// then the three output ranges [s0*W, (s0+256)*W) -- contiguous bytes -- are produced one 32-bit word
+// per thread, so a wavefront's stores are 256 contiguous bytes; the residue bytes come through the
+// vector cache (neighbouring sites of a protein share most of their windows).
+// seq_off == nullptr: one protein of length a.L (site_protein is then not read).
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void assemble_kernel(const uint8_t* __restrict__ codes, int64_t L,
-                                                       int64_t esm_rows,
-                                                       const int32_t* __restrict__ positions,
-                                                       int64_t n, uint8_t* __restrict__ t21,
-                                                       uint8_t* __restrict__ t33,
-                                                       uint8_t* __restrict__ t51,
-                                                       int32_t* __restrict__ esm_row) {
-    const int64_t total = n * (21 + 33 + 51);
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        uint8_t* dst;
-        int w;
-        int64_t local;
-        if (idx < n * 21) {
-            dst = t21; w = 21; local = idx;
-        } else if (idx < n * (21 + 33)) {
-            dst = t33; w = 33; local = idx - n * 21;
+template <int W>
+__device__ __forceinline__ void assemble_window(const AssembleArgs& a, uint8_t* __restrict__ dst, int64_t s0, int rows,
+                                                const int64_t* s_base, const int32_t* s_len, const int32_t* s_pos0,
+                                                bool words) {
+    constexpr int half = (W - 1) / 2;
+    const int bytes = rows * W;
+    uint8_t* out = dst + s0 * W;
+    for (int d = threadIdx.x; 4 * d < bytes; d += blockDim.x) {
+        int sl = (4 * d) / W;
+        int c = 4 * d - sl * W;
+        uint32_t v = 0;
+        uint8_t b4[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            uint8_t code = 20;
+            if (4 * d + b < bytes) {
+                const int i = s_pos0[sl] - half + c;
+                if (i >= 0 && i < s_len[sl]) {
+                    code = a.codes[s_base[sl] + i];
+                    code = code > 20 ? 20 : code;
+                }
+            }
+            b4[b] = code;
+            v |= (uint32_t)code << (8 * b);
+            if (++c == W) { c = 0; ++sl; }
+        }
+        if (words && 4 * d + 3 < bytes) {
+            *reinterpret_cast<uint32_t*>(out + 4 * d) = v;
         } else {
-            dst = t51; w = 51; local = idx - n * (21 + 33);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (4 * d + b < bytes) out[4 * d + b] = b4[b];
         }
-        const int64_t site = local / w;
-        const int c = (int)(local - site * w);
-        const int64_t pos = positions[site];
-        const int64_t i = pos - 1 - (w - 1) / 2 + c;
-        uint8_t code = 20;
-        if (i >= 0 && i < L) {
-            code = codes[i];
-            if (code > 20) code = 20;
+    }
+}
+
+__global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
+    __shared__ int64_t s_base[256];
+    __shared__ int32_t s_len[256];
+    __shared__ int32_t s_pos0[256];
+    const int tid = threadIdx.x;
+    const int64_t tiles = (a.n + 255) / 256;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t s0 = tile * 256;
+        const int rows = (int)min((int64_t)256, a.n - s0);
+        if (tid < rows) {
+            const int64_t site = s0 + tid;
+            const int32_t pos = a.positions[site];
+            int64_t base = 0, len = a.L, erow0 = 0, erows = a.esm_rows;
+            if (a.seq_off) {
+                const int32_t p = a.site_protein[site];
+                base = a.seq_off[p];
+                len = a.seq_off[p + 1] - base;
+                erow0 = a.esm_off[p];
+                erows = a.esm_off[p + 1] - erow0;
+            }
+            s_base[tid] = base;
+            s_len[tid] = (int32_t)len;
+            s_pos0[tid] = pos - 1;
+            a.esm_row[site] = (pos - 1 < erows) ? (int32_t)(erow0 + pos - 1) : -1;
         }
-        dst[local] = code;
-        if (w == 21 && c == 0) esm_row[site] = (pos - 1 < esm_rows) ? (int32_t)(pos - 1) : -1;
+        __syncthreads();
+        assemble_window<21>(a, a.t21, s0, rows, s_base, s_len, s_pos0, a.words);
+        assemble_window<33>(a, a.t33, s0, rows, s_base, s_len, s_pos0, a.words);
+        assemble_window<51>(a, a.t51, s0, rows, s_base, s_len, s_pos0, a.words);
+        __syncthreads();
     }
 }
 
@@ -813,21 +852,25 @@ __global__ __launch_bounds__(256) void assemble_kernel(const uint8_t* __restrict
 
 static constexpr size_t kBranchLds = (2 * kTileRows * kLdsStride + kTileRows) * sizeof(float) + kVecsF4 * 16;
 
+// the LDS opt-in is per device: remember which devices of this process have it
+template <int W>
+static hipError_t branch_attr(int dev) {
+    static bool attr_done_dev[64] = {};
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (attr_done_dev[dev]) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&branch_kernel<W>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBranchLds);
+    if (e == hipSuccess) attr_done_dev[dev] = true;
+    return e;
+}
+
 template <int W>
 static hipError_t launch_branch_t(const float* params, const uint8_t* tok, int64_t n, float* out,
                                   int ldo, int col_off, hipStream_t st) {
-    // the LDS opt-in is per device: remember which devices of this process have it
-    static bool attr_done_dev[64] = {};
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    bool& attr_done = attr_done_dev[dev];
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&branch_kernel<W>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)kBranchLds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if ((e = branch_attr<W>(dev)) != hipSuccess) return e;
     constexpr int S = kTileRows / W;
     const int64_t blocks = (n + S - 1) / S;
     if (blocks == 0) return hipSuccess;
@@ -875,16 +918,27 @@ hipError_t launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_assemble(const uint8_t* codes, int64_t L, int64_t esm_rows,
-                           const int32_t* positions, int64_t n, uint8_t* t21, uint8_t* t33,
-                           uint8_t* t51, int32_t* esm_row, hipStream_t st) {
-    if (n == 0) return hipSuccess;
-    const int64_t total = n * 105;
-    int64_t blocks = (total + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)blocks), dim3(256), 0, st, codes, L, esm_rows,
-                       positions, n, t21, t33, t51, esm_row);
+hipError_t launch_assemble(const AssembleArgs& a, hipStream_t st) {
+    if (a.n == 0) return hipSuccess;
+    int64_t blocks = (a.n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    AssembleArgs k = a;
+    // whole 32-bit words can be stored when every output array starts on a 4-byte boundary (a tile's byte
+    // range starts at a multiple of 256*W)
+    k.words = ((reinterpret_cast<uintptr_t>(a.t21) | reinterpret_cast<uintptr_t>(a.t33) |
+                reinterpret_cast<uintptr_t>(a.t51)) & 3) == 0;
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)blocks), dim3(256), 0, st, k);
     return hipGetLastError();
+}
+
+// Per-device kernel attributes (the LDS opt-in of the fp32 branch kernels) ahead of the first launch.
+hipError_t prepare_kernels() {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if ((e = branch_attr<21>(dev)) != hipSuccess) return e;
+    if ((e = branch_attr<33>(dev)) != hipSuccess) return e;
+    return branch_attr<51>(dev);
 }
 
 }  // namespace dptm

@@ -118,6 +118,48 @@ class Model:
             return np.zeros((0, self.spec.n_classes), dtype=np.float32)
         return self.scorer.score_protein(codes, table, pos.astype(np.int32), st)
 
+    def predict_proteins(self, proteins) -> List[np.ndarray]:
+        """Many proteins in ONE native call (``dptm_score_proteins``), instead of the per-protein loop
+        around ``predict_ptm_sites`` (predict.py:584-612).  ``proteins`` is a sequence of
+        ``(sequence, positions, struct_features, esm_table_or_None)`` with the meaning of
+        ``predict_protein``; returns one float32 ``[n_i, 2]`` array per protein, equal to what
+        ``predict_protein`` gives for it."""
+        f = self.spec.struct_feature_dim
+        codes, pos_all, prot_all, st_all, tables, counts = [], [], [], [], [], []
+        seq_off, esm_off = [0], [0]
+        for k, (sequence, positions, struct_features, esm_table) in enumerate(proteins):
+            pos = np.ascontiguousarray(np.asarray(positions, dtype=np.int64)).reshape(-1)
+            if pos.size and (pos.min() < 1 or pos.max() > len(sequence)):
+                raise IndexError(f"protein {k}: position outside the sequence (predict.py:535 raises IndexError)")
+            st = _as_features(np.asarray(struct_features).reshape(-1, f), f, f"protein {k}: struct_features")
+            if len(st) != len(pos):
+                raise ValueError(f"protein {k}: struct_features and positions differ in length")
+            codes.append(encode_sequence(sequence))
+            seq_off.append(seq_off[-1] + len(sequence))
+            rows = 0
+            if esm_table is not None and len(esm_table):
+                t = _as_features(esm_table, self.spec.esm_dim, f"protein {k}: esm_table")
+                tables.append(t)
+                rows = len(t)
+            esm_off.append(esm_off[-1] + rows)
+            pos_all.append(pos.astype(np.int32))
+            prot_all.append(np.full(len(pos), k, dtype=np.int32))
+            st_all.append(st)
+            counts.append(len(pos))
+        n = int(sum(counts))
+        if n == 0:
+            return [np.zeros((0, self.spec.n_classes), dtype=np.float32) for _ in counts]
+        if getattr(self, "_dirty", False):
+            self._pull_trained_weights()
+            self._dirty = False
+        cat = lambda parts, dt, shape: (np.ascontiguousarray(np.concatenate(parts), dtype=dt) if parts
+                                        else np.zeros(shape, dtype=dt))
+        out = self.scorer.score_proteins(cat(codes, np.uint8, (0,)), np.asarray(seq_off, dtype=np.int64),
+                                         cat(tables, np.float32, (0, self.spec.esm_dim)) if tables else None,
+                                         np.asarray(esm_off, dtype=np.int64), cat(pos_all, np.int32, (0,)),
+                                         cat(prot_all, np.int32, (0,)), cat(st_all, np.float32, (0, f)))
+        return [a for a in np.split(out, np.cumsum(counts)[:-1])]
+
     # -- training (trainer.py:304-339)
     def compile(self, optimizer=None, loss=None, metrics=None, **_ignored) -> None:
         """``model.compile(optimizer=AdamW(...), loss=..., metrics=...)`` (trainer.py:304-309).

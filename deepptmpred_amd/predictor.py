@@ -201,6 +201,34 @@ class PTMPredictor:
         return pd.DataFrame(rows, columns=["protein_id", "position", "residue", "probability", "prediction"])
 
 
+    def predict_ptm_sites_batch(self, proteins):
+        """The loop a proteome run makes around ``predict_ptm_sites`` (predict.py:584-612), as ONE scoring call.
+        ``proteins``: iterable of dicts with ``protein_id``, ``protein_sequence`` and optionally ``positions``,
+        ``pdb_path``, ``struct_features`` (same meaning as the arguments of ``predict_ptm_sites``).  Returns one
+        DataFrame with the reference's columns, proteins in input order."""
+        import pandas as pd
+        jobs, meta = [], []
+        for p in proteins:
+            pid, seq = p["protein_id"], p["protein_sequence"]
+            positions = p.get("positions")
+            if positions is None:
+                positions = [i + 1 for i, aa in enumerate(seq) if aa in self.config.target_aa]
+            positions = list(positions)
+            st = p.get("struct_features")
+            if st is None:
+                loader = self.data_loader
+                if p.get("pdb_path"):          # a structure calculator is per protein
+                    loader = PTMPredictDataLoader(self.config, None, self.data_loader.sasa_backend, self.data_loader.device)
+                    loader.init_pyrosetta(p["pdb_path"])
+                st = loader._generate_structural_features(positions)
+            jobs.append((seq, positions, st, self.data_loader.load_custom_esm(pid)))
+            meta.append((pid, seq, positions))
+        probas = self.model.predict_proteins(jobs)
+        rows = [{"protein_id": pid, "position": pos, "residue": seq[pos - 1], "probability": pr, "prediction": 1 if pr >= 0.5 else 0}
+                for (pid, seq, positions), proba in zip(meta, probas) for pos, pr in zip(positions, proba[:, 1])]
+        return pd.DataFrame(rows, columns=["protein_id", "position", "residue", "probability", "prediction"])
+
+
 def run_protein(ptm_type: str, project_root: str, pdb_path: str, model_path: Optional[str] = None, out_dir: Optional[str] = None):
     """What ``python predict.py`` does for one PDB file (predict.py:615-659): returns the
     DataFrame and writes ``results/{id}_{ptm}_predictions.csv``."""

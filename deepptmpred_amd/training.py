@@ -82,6 +82,11 @@ class NativeBackend:
         ptr, count = self.trainer.grad_buffer()
         self._grad_view = self._wrap(ptr, count)
         self._stage = None
+        # One stream of its own carries staging copies, forward/backward, the gradient all-reduce and the
+        # optimizer update, so they are ordered by the stream and not by host waits.  (A NULL stream handle
+        # means "the trainer's private stream" to the library, which RCCL's all-reduce would not be ordered
+        # against: the handle passed down is therefore never 0.)
+        self.stream = torch.cuda.Stream(device=self.device)
 
     def _wrap(self, ptr: int, count: int):
         """torch view of library-owned device memory (for the RCCL all-reduce)."""
@@ -105,19 +110,20 @@ class NativeBackend:
                            t.empty((mb,), dtype=t.int32, device=self.device)]
         n = len(labels)
         d = self._stage
-        for buf, a in zip(d[:5], x):
-            buf[:n].copy_(t.from_numpy(np.ascontiguousarray(a, dtype=np.uint8 if buf.dtype == t.uint8 else np.float32)),
-                          non_blocking=False)
-        d[5][:n].copy_(t.from_numpy(np.ascontiguousarray(labels, dtype=np.int32)))
-        lab = d[5]
         o = _native.TrainOpts()
         o.seed = seed & 0xFFFFFFFF
         o.rate_embed, o.rate_conv, o.rate_tb, o.rate_dense = rates.embed, rates.conv, rates.tb, rates.dense
         o.n_global, o.n_pos_global = int(n_global), int(n_pos_global)
         o.l2, o.l2_scale = l2, l2_scale
-        st = t.cuda.current_stream().cuda_stream
-        loss = self.trainer.forward_backward(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
-                                             d[4].data_ptr(), lab.data_ptr(), len(labels), o, True, st)
+        self.stream.wait_stream(t.cuda.current_stream(self.device))
+        with t.cuda.stream(self.stream):
+            for buf, a in zip(d[:5], x):
+                buf[:n].copy_(t.from_numpy(np.ascontiguousarray(a, dtype=np.uint8 if buf.dtype == t.uint8 else np.float32)),
+                              non_blocking=False)
+            d[5][:n].copy_(t.from_numpy(np.ascontiguousarray(labels, dtype=np.int32)))
+            loss = self.trainer.forward_backward(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
+                                                 d[4].data_ptr(), d[5].data_ptr(), len(labels), o, True,
+                                                 self.stream.cuda_stream)
         return loss
 
     def enable_sync_batchnorm(self, group=None) -> None:
@@ -134,7 +140,7 @@ class NativeBackend:
             v = views.get((ptr, count))
             if v is None:
                 v = views[(ptr, count)] = self._wrap(ptr, count)
-            s = t.cuda.ExternalStream(stream, device=self.device) if stream else t.cuda.default_stream(self.device)
+            s = t.cuda.ExternalStream(stream, device=self.device) if stream else self.stream
             with t.cuda.stream(s):
                 if on_device:
                     dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
@@ -149,11 +155,19 @@ class NativeBackend:
         self.trainer.set_allreduce(None)
 
     def allreduce_grads(self, group=None) -> None:
+        """ONE all-reduce (sum) of the flat gradient buffer, on the backend's stream (RCCL); host backends
+        (gloo: CPU tests, one-GPU rehearsals) go through host memory."""
         import torch.distributed as dist
-        dist.all_reduce(self._grad_view, op=dist.ReduceOp.SUM, group=group)
+        with self.torch.cuda.stream(self.stream):
+            if dist.get_backend(group) == "nccl":
+                dist.all_reduce(self._grad_view, op=dist.ReduceOp.SUM, group=group)
+            else:
+                h = self._grad_view.cpu()                  # waits for the gradients on this stream
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                self._grad_view.copy_(h)
 
     def apply(self, lr: float, weight_decay: float, stat_scale: float = 1.0) -> None:
-        self.trainer.apply(lr, weight_decay, 1.0, stat_scale, self.torch.cuda.current_stream().cuda_stream)
+        self.trainer.apply(lr, weight_decay, 1.0, stat_scale, self.stream.cuda_stream)
 
     def weights(self) -> Dict[str, np.ndarray]:
         return unpack_blob(self.trainer.get_weights(), self.spec)

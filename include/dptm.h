@@ -119,6 +119,40 @@ int dptm_assemble_device(dptm_handle* h, const uint8_t* codes, int64_t L, int64_
                          const int32_t* positions, int64_t n, uint8_t* tok21, uint8_t* tok33,
                          uint8_t* tok51, int32_t* esm_row, void* stream);
 
+/* Many proteins per call: replaces the per-protein loop a proteome run makes around
+ * predict_ptm_sites (pred/train_PTM/predict.py:584-612; window assembly predict.py:529-560, ESM row
+ * gather predict.py:487-501) with ONE call whose sites may belong to any number of proteins.
+ *   codes:        uint8 [seq_offsets[P]]  residue codes of all proteins, concatenated;
+ *   seq_offsets:  int64 [P+1], seq_offsets[0] = 0: protein p owns codes[seq_offsets[p] .. seq_offsets[p+1]);
+ *   esm_tables:   float32 [esm_offsets[P]][1280]  per-residue tables, concatenated (NULL if none has one);
+ *   esm_offsets:  int64 [P+1], esm_offsets[0] = 0: first table row of protein p; a protein without a
+ *                 table has esm_offsets[p+1] == esm_offsets[p] (its sites get zero rows, predict.py:498-500),
+ *                 and a site beyond its protein's table gets a zero row (predict.py:493);
+ *   positions:    int32 [n], 1-based within the site's protein;  site_protein: int32 [n], 0..P-1;
+ *   strct: float32 [n][8];  out: float32 [n][2], rows in input order.
+ * Sites need not be grouped by protein.  Results equal those of dptm_score_protein called per
+ * protein.  The host form checks every offset, protein index and position (DPTM_EINVAL, nothing
+ * scored) and moves only the ESM rows the sites use across PCIe, double-buffered; the device
+ * form (DEVICE pointers, same alignment rules as above, offsets 8-byte aligned, enqueued on
+ * `stream`) expects validated input and gathers rows from the resident tables inside the ESM layer. */
+int dptm_score_proteins(dptm_handle* h, const uint8_t* codes, const int64_t* seq_offsets,
+                        const float* esm_tables, const int64_t* esm_offsets, int64_t n_proteins,
+                        const int32_t* positions, const int32_t* site_protein, const float* strct,
+                        int64_t n, float* out);
+
+int dptm_score_proteins_device(dptm_handle* h, const uint8_t* codes, const int64_t* seq_offsets,
+                               const float* esm_tables, const int64_t* esm_offsets, int64_t n_proteins,
+                               const int32_t* positions, const int32_t* site_protein, const float* strct,
+                               int64_t n, float* out, void* stream);
+
+/* Window assembly alone for sites of many proteins (predict.py:529-560, 487-501 on the device).
+ * DEVICE pointers, validated input.  Writes tok21/tok33/tok51 uint8 [n][W] and esm_row int32 [n]
+ * (row of the concatenated tables, or -1 for a zero row).  One launch covers all n sites. */
+int dptm_assemble_proteins_device(dptm_handle* h, const uint8_t* codes, const int64_t* seq_offsets,
+                                  const int64_t* esm_offsets, const int32_t* positions,
+                                  const int32_t* site_protein, int64_t n, uint8_t* tok21, uint8_t* tok33,
+                                  uint8_t* tok51, int32_t* esm_row, void* stream);
+
 /* Blocks until everything enqueued on the handle's own stream has finished. */
 int dptm_sync(dptm_handle* h);
 
