@@ -188,7 +188,7 @@ def test_bad_tables_are_rejected(model):
     with pytest.raises(ValueError, match="names protein"):
         sc.score_proteins(codes, off, None, zero, one(1), one(2), st)
     with pytest.raises(ValueError, match="decrease"):
-        sc.score_proteins(codes, np.array([0, 8, 6], dtype=np.int64), None, zero, one(1), one(0), st)
+        sc.score_proteins(codes, np.array([0, 14, 12], dtype=np.int64), None, zero, one(1), one(0), st)
     with pytest.raises(ValueError):
         sc.score_proteins(codes, np.array([0, 6, 11], dtype=np.int64), None, zero, one(1), one(0), st)
     ok = sc.score_proteins(codes, off, None, zero, one(6), one(1), st)         # still works afterwards
