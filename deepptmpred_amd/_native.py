@@ -27,6 +27,7 @@ EXPORTS = (
     "dptm_weight_count", "dptm_create", "dptm_destroy", "dptm_score", "dptm_score_protein",
     "dptm_score_device", "dptm_score_protein_device", "dptm_assemble_device", "dptm_sync",
     "dptm_score_proteins", "dptm_score_proteins_device", "dptm_assemble_proteins_device",
+    "dptm_score_device_noalloc", "dptm_noalloc_max_sites",
     "dptm_profile_begin", "dptm_profile_end", "dptm_chunk_sites", "dptm_last_error",
     "dptm_set_precision", "dptm_trainer_create", "dptm_trainer_destroy", "dptm_trainer_forward_backward",
     "dptm_trainer_grad_buffer", "dptm_trainer_param_floats", "dptm_trainer_apply",
@@ -126,6 +127,10 @@ def load_library() -> C.CDLL:
     lib.dptm_score_protein.argtypes = [vp, u8p, i64, f32p, i64, i32p, f32p, i64, f32p]
     lib.dptm_score_device.restype = C.c_int
     lib.dptm_score_device.argtypes = [vp, u8p, u8p, u8p, f32p, f32p, i64, f32p, vp]
+    lib.dptm_score_device_noalloc.restype = C.c_int
+    lib.dptm_score_device_noalloc.argtypes = [vp, u8p, u8p, u8p, f32p, f32p, i64, f32p, vp]
+    lib.dptm_noalloc_max_sites.restype = C.c_int64
+    lib.dptm_noalloc_max_sites.argtypes = []
     lib.dptm_score_protein_device.restype = C.c_int
     lib.dptm_score_protein_device.argtypes = [vp, u8p, i64, f32p, i64, i32p, f32p, i64, f32p, vp]
     lib.dptm_assemble_device.restype = C.c_int
@@ -316,6 +321,13 @@ class Scorer:
         rc = self._lib.dptm_score_device(self._h, tok21, tok33, tok51, strct, esm, n, out,
                                          C.c_void_p(stream or None))
         _check(self._lib, rc, "dptm_score_device")
+
+    def score_device_noalloc(self, tok21, tok33, tok51, strct, esm, n, out, stream=0) -> None:
+        """``score_device`` on the library's static workspace: allocates nothing, at most
+        ``dptm_noalloc_max_sites()`` sites per call."""
+        rc = self._lib.dptm_score_device_noalloc(self._h, tok21, tok33, tok51, strct, esm, n, out,
+                                                 C.c_void_p(stream or None))
+        _check(self._lib, rc, "dptm_score_device_noalloc")
 
     def score_protein_device(self, codes, L, esm_table, esm_rows, positions, strct, n, out,
                              stream=0) -> None:

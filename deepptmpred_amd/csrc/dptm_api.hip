@@ -170,6 +170,15 @@ struct Workspace {
 };
 constexpr int64_t kWorkspaceFloatsPerSite = kConcat + kEsm1 + kT1 + kT2;   // 1856
 
+// Workspace of dptm_score_device_noalloc: the per-site layers' activations for at most kNoAllocMaxSites
+// sites (30.4 MB), resident on every GPU the library runs on until the process ends.  In host code the
+// array's name is only a stand-in; its address on a device is asked for once per device (dptm_create) and
+// kept in g_scratch_ptr, which is what kernels and copies are given.
+constexpr int64_t kNoAllocMaxSites = 4096;
+static __device__ __align__(256) float scratch[kNoAllocMaxSites * kWorkspaceFloatsPerSite];
+constexpr int kMaxDevices = 64;
+float* g_scratch_ptr[kMaxDevices] = {};
+
 }  // namespace
 
 struct dptm_handle {
@@ -770,6 +779,14 @@ int dptm_create(const void* weights, size_t nbytes, const dptm_spec* spec, int d
     if ((rc = dalloc((void**)&h->ws.h1, kChunkSites * (size_t)kEsm1 * 4))) return bail(rc);
     if ((rc = dalloc((void**)&h->ws.t1, kChunkSites * (size_t)kT1 * 4))) return bail(rc);
     if ((rc = dalloc((void**)&h->ws.t2, kChunkSites * (size_t)kT2 * 4))) return bail(rc);
+    if (device >= kMaxDevices) return bail(fail(DPTM_EINVAL, "dptm_create: device index beyond the library's table"));
+    if (!g_scratch_ptr[device]) {     // this device's copy of the static workspace (device `device` is current)
+        float* sp = nullptr;
+        hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&sp), HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !sp)
+            return bail(fail(DPTM_EHIP, std::string("dptm_create: hipGetSymbolAddress(scratch): ") + hipGetErrorString(e)));
+        g_scratch_ptr[device] = sp;
+    }
     if (hipError_t e = prepare_kernels(); e != hipSuccess)
         return bail(fail(DPTM_EHIP, std::string("dptm_create: kernel set-up failed: ") + hipGetErrorString(e)));
     if ((rc = dalloc((void**)&h->d_zero_row, kEsm * 4))) return bail(rc);
@@ -831,6 +848,45 @@ int dptm_score_device(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33
     return DPTM_OK;
 } catch (...) {
     return on_exception("dptm_score_device");
+}
+
+int64_t dptm_noalloc_max_sites(void) { return kNoAllocMaxSites; }
+
+int dptm_score_device_noalloc(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
+                              const float* strct, const float* esm, int64_t n, float* out, void* stream) try {
+    if (!h) return fail(DPTM_EINVAL, "dptm_score_device_noalloc: NULL handle");
+    if (n < 0) return fail(DPTM_EINVAL, "dptm_score_device_noalloc: n < 0");
+    if (n > kNoAllocMaxSites) {
+        char msg[160];
+        std::snprintf(msg, sizeof msg, "dptm_score_device_noalloc: %lld sites, the static workspace holds at most %lld per call",
+                      (long long)n, (long long)kNoAllocMaxSites);
+        return fail(DPTM_EINVAL, msg);
+    }
+    if (n == 0) return DPTM_OK;
+    if (!tok21 || !tok33 || !tok51 || !strct || !esm || !out)
+        return fail(DPTM_EINVAL, "dptm_score_device_noalloc: NULL buffer");
+    if (misaligned(strct, 16) || misaligned(esm, 16) || misaligned(out, 8))
+        return fail(DPTM_EINVAL, "dptm_score_device_noalloc: struct / esm must be 16-byte aligned, out 8-byte aligned");
+    float* base = g_scratch_ptr[h->device];
+    if (!base) return fail(DPTM_EHIP, "dptm_score_device_noalloc: no workspace address for this device");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    // every row the layers read was written earlier in the same call (rows past n are never read), so nothing in
+    // the workspace has to start at zero
+    Workspace ws;
+    ws.concat = base;
+    ws.h1 = ws.concat + kNoAllocMaxSites * kConcat;
+    ws.t1 = ws.h1 + kNoAllocMaxSites * kEsm1;
+    ws.t2 = ws.t1 + kNoAllocMaxSites * kT1;
+    struct Plain {       // no side streams, no timing events: this call creates nothing
+        dptm_handle* h;
+        ~Plain() { h->plain = false; }
+    } plain{h};
+    h->plain = true;
+    const uint8_t* tok[3] = {tok21, tok33, tok51};
+    return score_chunk(h, ws, tok, strct, esm, kEsm, nullptr, n, out, st);
+} catch (...) {
+    return on_exception("dptm_score_device_noalloc");
 }
 
 int dptm_assemble_device(dptm_handle* h, const uint8_t* codes, int64_t L, int64_t esm_rows,

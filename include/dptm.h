@@ -108,6 +108,19 @@ int dptm_score_device(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33
                       const uint8_t* tok51, const float* strct, const float* esm, int64_t n,
                       float* out, void* stream);
 
+/* dptm_score_device for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments,
+ * same kernels and bit-identical results, but the per-site layers' activations live in a static
+ * device array of the library (30.4 MB per GPU, held until the process ends) instead of the handle's
+ * buffers, and the call creates no stream or event and never allocates or frees.  At most
+ * dptm_noalloc_max_sites() = 4096 sites per call; more fails with DPTM_EINVAL and nothing is enqueued.
+ * All calls on one GPU -- from any handle -- share that array: calls that overlap in time on one GPU
+ * race; order them on one stream or with events.  Per-kernel profiling does not see these calls. */
+int dptm_score_device_noalloc(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33,
+                              const uint8_t* tok51, const float* strct, const float* esm, int64_t n,
+                              float* out, void* stream);
+int64_t dptm_noalloc_max_sites(void);
+
 int dptm_score_protein_device(dptm_handle* h, const uint8_t* codes, int64_t L,
                               const float* esm_table, int64_t esm_rows, const int32_t* positions,
                               const float* strct, int64_t n, float* out, void* stream);
