@@ -172,3 +172,99 @@ def test_damaged_files_raise_format_error(tmp_path):
     with pytest.raises(H5FormatError):
         bad.write_bytes(b"not an hdf5 file at all")
         keras_h5.read_keras_h5(str(bad))
+
+
+def test_written_layer_order_is_keras_depth_order(tmp_path):
+    """Keras-2 load_weights pairs the file's weighted layers with model.layers by position, and a functional
+    model's layers are sorted by depth, ties by the walk from the output (functional.py, _map_graph_network).
+    Hand-derived for model.py:143-210: depth 26 inputs, 25 embeddings, 24 position embeddings, 23 spatial
+    dropouts, 22 first 3-tap convs, 21 their BatchNorms, 20 spatial dropouts, 19 second 3-tap convs, 18 {their
+    BatchNorm, the shortcut conv} per branch (Add lists x before shortcut), 17 adds, 16/15 transformer blocks,
+    14 pooling Dense, ... 11 {struct_input, ESM Dense 512}, 10 {struct Dense, ESM BatchNorm}, 9 {struct
+    BatchNorm}, 8 {ESM Dense 256}, 5 trunk Dense 512, 4 BN, 2 Dense 256, 1 BN, 0 head."""
+    from deepptmpred_amd.keras_h5 import keras_model_layers
+    want = ["embedding", "embedding_1", "embedding_2", "position_embedding", "position_embedding_1", "position_embedding_2",
+            "conv1d_1", "conv1d_4", "conv1d_7", "batch_normalization", "batch_normalization_2", "batch_normalization_4",
+            "conv1d_2", "conv1d_5", "conv1d_8",
+            "batch_normalization_1", "conv1d", "batch_normalization_3", "conv1d_3", "batch_normalization_5", "conv1d_6",
+            "transformer_block", "transformer_block_2", "transformer_block_4",
+            "transformer_block_1", "transformer_block_3", "transformer_block_5",
+            "dense_12", "dense_25", "dense_38", "dense_40", "dense_39", "batch_normalization_7", "batch_normalization_6",
+            "dense_41", "dense_42", "batch_normalization_8", "dense_43", "batch_normalization_9", "dense_44"]
+    layers = keras_model_layers()
+    assert len(layers) == 77 and len(set(layers)) == 77
+    assert layers[:3] == ["seq_input_21", "seq_input_33", "seq_input_51"] and layers[-1] == "dense_44"
+    assert layers.index("esm_input") > layers.index("activation_2") and layers.index("struct_input") > layers.index("repeat_vector_2")
+    weighted = set(n for n, _ in keras_layer_table())
+    assert [n for n in layers if n in weighted] == want
+    p = str(tmp_path / "o.h5")
+    write_keras_h5(p, spec.synthetic_weights(2))
+    got = [bytes(x).rstrip(b"\x00").decode() for x in H5File(p)["model_weights"].attrs["layer_names"]]
+    assert got == want
+
+
+def _renumbered_tree(w, offsets, inner_shuffle=False):
+    """The Keras layout with every class's layer numbers shifted (a model built in a session that already held
+    layers), layer_names in depth order; optionally the weights inside a transformer block listed in another order."""
+    from deepptmpred_amd.keras_h5 import _split_suffix, keras_model_layers
+    table = dict(keras_layer_table())
+
+    def ren(name):
+        cls, k = _split_suffix(name)
+        return f"{cls}_{k + offsets[cls]}" if cls in offsets else name
+
+    def ren_path(kn):
+        return "/".join(ren(part) if ":" not in part else part for part in kn.split("/"))
+
+    order = [n for n in keras_model_layers() if n in table]
+    ds, attrs = {}, {("/model_weights", "layer_names"): [ren(n).encode() for n in order]}
+    for ln in order:
+        pairs = list(table[ln])
+        if inner_shuffle and ln.startswith("transformer_block"):
+            pairs = pairs[8:12] + pairs[:8] + pairs[12:]            # FFN first, then the attention, then the norms
+        attrs[(f"/model_weights/{ren(ln)}", "weight_names")] = [ren_path(kn).encode() for kn, _ in pairs]
+        for kn, canon in pairs:
+            ds[f"/model_weights/{ren(ln)}/{ren_path(kn)}"] = w[canon]
+    return ds, attrs
+
+
+@pytest.mark.parametrize("inner_shuffle", [False, True])
+def test_reader_falls_back_to_creation_order_and_shapes(tmp_path, inner_shuffle):
+    """A checkpoint whose layers are dense_137.., transformer_block_23.. (not a fresh session) loads to the same
+    dict: classes and creation order identify the layers, shapes are checked, and inside a transformer block the
+    attention matrices are told apart by their Dense numbers rather than by their place in weight_names."""
+    w = spec.synthetic_weights(13)
+    offsets = {"dense": 137, "transformer_block": 23, "conv1d": 9, "batch_normalization": 10, "embedding": 3,
+               "position_embedding": 3, "multi_head_self_attention": 23, "layer_normalization": 46}
+    ds, attrs = _renumbered_tree(w, offsets, inner_shuffle)
+    p = str(tmp_path / "renumbered.h5")
+    wr = H5Writer()
+    for k, v in ds.items():
+        wr.create_dataset(k, v)
+    for (o, n), v in attrs.items():
+        wr.set_attr(o, n, v)
+    wr.save(p)
+    back = read_keras_h5(p)
+    assert set(back) == set(w) and all(np.array_equal(back[k], w[k]) for k in w)
+    if LIB is not None:                               # the same file produced by the real library
+        p2 = str(tmp_path / "renumbered_lib.h5")
+        h5_ctypes.write_tree(LIB, p2, ds, attrs)
+        back = read_keras_h5(p2)
+        assert all(np.array_equal(back[k], w[k]) for k in w)
+
+
+def test_fallback_reports_a_wrong_layer_count(tmp_path):
+    w = spec.synthetic_weights(13)
+    ds, attrs = _renumbered_tree(w, {"dense": 50})
+    victim = "/model_weights/dense_94"                 # the head: dense_44 + 50
+    ds = {k: v for k, v in ds.items() if not k.startswith(victim + "/")}
+    attrs = {k: v for k, v in attrs.items() if k[0] != victim}
+    wr = H5Writer()
+    for k, v in ds.items():
+        wr.create_dataset(k, v)
+    for (o, n), v in attrs.items():
+        wr.set_attr(o, n, v)
+    p = str(tmp_path / "short.h5")
+    wr.save(p)
+    with pytest.raises(H5FormatError, match="dense"):
+        read_keras_h5(p)
