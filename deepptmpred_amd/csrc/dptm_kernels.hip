@@ -13,111 +13,11 @@
 #include <hip/hip_runtime.h>
 
 #include "dptm_layout.h"
+#include "dptm_mfma.h"
 #include "dptm_phase.h"
 #include "dptm_kernels.h"
 
 namespace dptm {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ void mfma(f32x16& acc, float a, float b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-}
-
-constexpr float kQScale = 0.25f * 1.44269504088896340736f;  // log2(e) / sqrt(head_dim)
-
-__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-
-// keras 'swish': x * sigmoid(x)
-__device__ __forceinline__ float swishf(float x) { return x * fast_rcp(1.0f + __expf(-x)); }
-
-__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32); }
-
-// Exchange between the two half-waves: returns {a.lo|b.lo , a.hi|b.hi} (see
-// v_permlane32_swap: lanes 32-63 of the first operand swap with lanes 0-31 of the second).
-__device__ __forceinline__ void half_swap(float& a, float& b) {
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    a = __uint_as_float(r[0]);
-    b = __uint_as_float(r[1]);
-}
-
-// acc tile t (16 regs) <-> feature groups u = 4t..4t+3 of the chain layout
-template <int NT>
-__device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[NT], const f32x4* __restrict__ vec,
-                                              int h, int groups_per_half) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 b = vec[h * groups_per_half + 4 * t + g];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[t][4 * g + e] = b[e];
-        }
-}
-
-// acc[t] += W^T-tile(t) * X^T with X held in registers (chain layout, K8 groups of 8 feats).
-// Weight fragments are fetched DIST groups ahead of the MFMAs that consume them; the
-// sched_barrier at the end of every group pins that order so the L2 latency of a fetch is
-// covered by the 4*NT*DIST MFMAs issued after it.
-template <int K8, int NT, int DIST = 2>
-__device__ __forceinline__ void gemm_regs(f32x16 (&acc)[NT], const f32x4* __restrict__ wp,
-                                          const f32x4 (&x)[K8], int lane) {
-    f32x4 a[K8][NT];
-#pragma unroll
-    for (int u = 0; u < DIST && u < K8; ++u)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) a[u][t] = wp[(t * K8 + u) * 64 + lane];
-#pragma unroll
-    for (int u = 0; u < K8; ++u) {
-        if (u + DIST < K8) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) a[u + DIST][t] = wp[(t * K8 + u + DIST) * 64 + lane];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) mfma(acc[t], a[u][t][e], x[u][e]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-template <int NT>
-__device__ __forceinline__ void acc_to_x(const f32x16 (&acc)[NT], f32x4 (&x)[4 * NT]) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) x[4 * t + g][e] = acc[t][4 * g + e];
-}
-
-// keras LayerNormalization(epsilon=1e-6) over the 64 features of each row
-__device__ __forceinline__ void layernorm64(f32x4 (&x)[8], const f32x4* __restrict__ g,
-                                            const f32x4* __restrict__ b, int h) {
-    float s = 0.f;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += (x[u][0] + x[u][1]) + (x[u][2] + x[u][3]);
-    const float mean = xhalf_sum(s) * (1.0f / 64.0f);
-    float q = 0.f;
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float d = x[u][e] - mean;
-            x[u][e] = d;
-            q = fmaf(d, d, q);
-        }
-    const float var = xhalf_sum(q) * (1.0f / 64.0f);
-    const float inv = rsqrtf(var + 1e-6f);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const f32x4 gg = g[h * 8 + u], bb = b[h * 8 + u];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x[u][e] = fmaf(x[u][e] * inv, gg[e], bb[e]);
-    }
-}
 
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -773,12 +673,15 @@ __global__ __launch_bounds__(512) void dense_small_kernel(DenseArgs p) {
 // Window assembly (predict.py:529-560) and the ESM row index (predict.py:487-501) for sites of many
 // proteins at once: column c of the W-window of 1-based, protein-local position `pos` is residue
 // pos-1-(W-1)/2+c of that protein, or the padding code 20 outside 0..L-1 (also for codes > 20).
-// A workgroup owns 256 consecutive sites: their (sequence base, length, position) go to LDS once,
-// then the three output ranges [s0*W, (s0+256)*W) -- contiguous bytes -- are produced one 32-bit word
-// per thread, so a wavefront's stores are 256 contiguous bytes; the residue bytes come through the
-// vector cache (neighbouring sites of a protein share most of their windows).
+// A workgroup owns kAsmSites consecutive sites: their (sequence base, length, position) go to LDS once,
+// then the three output ranges [s0*W, (s0+kAsmSites)*W) -- contiguous bytes -- are produced one 32-bit
+// word per thread, so a wavefront's stores are 256 contiguous bytes; the residue bytes come through the
+// vector cache (neighbouring sites of a protein share most of their windows).  64 sites per workgroup
+// keep a 32,768-site pass at 512 workgroups (two per CU) with ~7 words per thread.
 // seq_off == nullptr: one protein of length a.L (site_protein is then not read).
 // ------------------------------------------------------------------------------------
+constexpr int kAsmSites = 64;
+
 template <int W>
 __device__ __forceinline__ void assemble_window(const AssembleArgs& a, uint8_t* __restrict__ dst, int64_t s0, int rows,
                                                 const int64_t* s_base, const int32_t* s_len, const int32_t* s_pos0,
@@ -816,14 +719,14 @@ __device__ __forceinline__ void assemble_window(const AssembleArgs& a, uint8_t* 
 }
 
 __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
-    __shared__ int64_t s_base[256];
-    __shared__ int32_t s_len[256];
-    __shared__ int32_t s_pos0[256];
+    __shared__ int64_t s_base[kAsmSites];
+    __shared__ int32_t s_len[kAsmSites];
+    __shared__ int32_t s_pos0[kAsmSites];
     const int tid = threadIdx.x;
-    const int64_t tiles = (a.n + 255) / 256;
+    const int64_t tiles = (a.n + kAsmSites - 1) / kAsmSites;
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int64_t s0 = tile * 256;
-        const int rows = (int)min((int64_t)256, a.n - s0);
+        const int64_t s0 = tile * kAsmSites;
+        const int rows = (int)min((int64_t)kAsmSites, a.n - s0);
         if (tid < rows) {
             const int64_t site = s0 + tid;
             const int32_t pos = a.positions[site];
@@ -920,11 +823,11 @@ hipError_t launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
 
 hipError_t launch_assemble(const AssembleArgs& a, hipStream_t st) {
     if (a.n == 0) return hipSuccess;
-    int64_t blocks = (a.n + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    int64_t blocks = (a.n + kAsmSites - 1) / kAsmSites;
+    if (blocks > 256 * 32) blocks = 256 * 32;
     AssembleArgs k = a;
     // whole 32-bit words can be stored when every output array starts on a 4-byte boundary (a tile's byte
-    // range starts at a multiple of 256*W)
+    // range starts at a multiple of 64*W)
     k.words = ((reinterpret_cast<uintptr_t>(a.t21) | reinterpret_cast<uintptr_t>(a.t33) |
                 reinterpret_cast<uintptr_t>(a.t51)) & 3) == 0;
     hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)blocks), dim3(256), 0, st, k);

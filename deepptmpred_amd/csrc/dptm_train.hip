@@ -16,6 +16,7 @@
 
 #include "../../include/dptm.h"
 #include "dptm_layout.h"
+#include "dptm_train_device.h"
 #include "dptm_train_kernels.h"
 
 using namespace dptm;
@@ -101,7 +102,9 @@ struct Arena {
     }
 };
 
-struct TbAct { float *x, *q, *k, *v, *prob, *o, *ao, *xh1, *inv1, *h, *f1, *u, *f2, *xh2, *inv2; };
+struct TbAct { float *x, *q, *k, *v, *prob, *o, *ao, *xh1, *inv1, *h, *xh2, *inv2; };
+// weight images of one TransformerBlock for the fused kernels (floats into dptm_trainer::P)
+struct TbImg { int64_t w1p, w2p, w2tp, w1tp; };
 struct BranchAct {
     int wlen;
     float *x0, *s, *a1, *y1, *z1, *a2, *y2, *x1, *mi1, *mi2;   // mi = mean|inv of a BatchNorm
@@ -117,6 +120,10 @@ struct dptm_trainer {
     int64_t max_batch = 0;
     PMap pm;
     float *W = nullptr, *G = nullptr, *M = nullptr, *V = nullptr;  // weights, grads (+ batch BN stats), Adam moments
+    float* P = nullptr;                   // weight images in MFMA fragment order, rebuilt from W every step
+    PackJob* pack_jobs = nullptr;         // device table of the images to build
+    int n_pack_jobs = 0;
+    TbImg tbimg[3][2];
     uint8_t* trainable = nullptr;
     Arena arena;
     BranchAct ba[3];
@@ -130,6 +137,7 @@ struct dptm_trainer {
     struct Scratch {
         float *g64a = nullptr, *g64b = nullptr, *g64c = nullptr, *g64d = nullptr, *g256 = nullptr;
         float *gq = nullptr, *gk = nullptr, *gv = nullptr, *bnsums_all = nullptr;
+        float* part = nullptr;            // partial parameter gradients of the fused backward kernels
     };
     Scratch sc[4];                        // [0..2] sequence branches, [3] per-site layers (BatchNorm sums only)
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
@@ -181,7 +189,7 @@ int alloc_acts(dptm_trainer* t) {
             TbAct& q = a.tb[i];
             ok &= need(q.q, R64) && need(q.k, R64) && need(q.v, R64) && need(q.prob, (size_t)B * 4 * kW[b] * kW[b]) &&
                   need(q.o, R64) && need(q.ao, R64) && need(q.xh1, R64) && need(q.inv1, R) && need(q.h, R64) &&
-                  need(q.f1, R * 256) && need(q.u, R * 256) && need(q.f2, R64) && need(q.xh2, R64) && need(q.inv2, R);
+                  need(q.xh2, (R + 31) / 32 * 2048) && need(q.inv2, R);
         }
         ok &= need(a.tb[1].x, R64) && need(a.xout, R64) && need(a.pa, R) && need(a.palpha, R);
         a.tb[0].x = a.x1;
@@ -197,7 +205,8 @@ int alloc_acts(dptm_trainer* t) {
         if (b == 3) break;
         const size_t RM = (size_t)B * kW[b];
         ok &= need(s.g64a, RM * 64) && need(s.g64b, RM * 64) && need(s.g64c, RM * 64) && need(s.g64d, RM * 64) &&
-              need(s.g256, RM * 256) && need(s.gq, RM * 64) && need(s.gk, RM * 64) && need(s.gv, RM * 64);
+              need(s.gq, RM * 64) && need(s.gk, RM * 64) && need(s.gv, RM * 64) &&
+              need(s.part, (size_t)t_ffn_bwd_max_parts() * kFfnPartStride);
     }
     ok &= need(t->dconcat, B * 576) && need(t->d512a, B * 512) && need(t->d512b, B * 512) && need(t->d256a, B * 256) &&
           need(t->d256b, B * 256) && need(t->d128, B * 128);
@@ -208,10 +217,11 @@ size_t arena_bytes(int64_t B) {
     size_t f = 0;
     for (int b = 0; b < 3; ++b) {
         const size_t R = (size_t)B * kW[b];
-        f += R * 64 * 9 + 2 * (R * 64 * 10 + R * 256 * 2 + R * 2 + (size_t)B * 4 * kW[b] * kW[b]) + R * 64 + R * 2;
+        f += R * 64 * 9 + 2 * (R * 64 * 9 + (R + 32) * 64 + R * 2 + (size_t)B * 4 * kW[b] * kW[b]) + R * 64 + R * 2;
+        f += (size_t)t_ffn_bwd_max_parts() * kFfnPartStride;
     }
     f += (size_t)B * (128 * 2 + 512 * 3 + 256 + 576 + 512 * 3 + 256 * 3 + 2);
-    f += (size_t)B * (21 + 33 + 51) * (64 * 7 + 256) + (4 + 2 * 10) * 1024 + (size_t)B * (576 + 1024 + 512 + 128);
+    f += (size_t)B * (21 + 33 + 51) * (64 * 7) + (4 + 2 * 10) * 1024 + (size_t)B * (576 + 1024 + 512 + 128);
     return f * sizeof(float) + (size_t)640 * 256 + (1 << 20);   // + per-allocation rounding slack
 }
 
@@ -350,13 +360,23 @@ int branch_fwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
         T_TRY(t_dropout(q.ao, R, 64, 64, 0, seed, b * 8 + 2 + 2 * i, rt.tb, c.st));
         T_TRY(t_ln_fwd(q.x, q.ao, c.w(w.ln1g), c.w(w.ln1b), q.h, q.xh1, q.inv1, R, c.st));
         {
-            GemmArgs g1 = ga(q.h, 64, c.w(w.f1k), 256, c.w(w.f1b), q.f1, 256, 0, R, 64, 256);
-            g1.act_out = q.u; g1.lda = 256;                                                   // u = swish(f1) in the epilogue
-            T_TRY(t_gemm(g1, false, c.st));
+            // feed-forward half in one launch: out = LN2(h + dropout(W2 swish(W1 h + b1) + b2))
+            const TbImg& im = t->tbimg[b][i];
+            FfnFwdArgs f;
+            f.h = q.h;
+            f.w1p = reinterpret_cast<const f32x4_tr*>(t->P + im.w1p);
+            f.w2p = reinterpret_cast<const f32x4_tr*>(t->P + im.w2p);
+            f.b1 = c.w(w.f1b); f.b2 = c.w(w.f2b); f.gamma = c.w(w.ln2g); f.beta = c.w(w.ln2b);
+            f.out = xout;
+            f.xhat = reinterpret_cast<f32x4_tr*>(q.xh2);
+            f.inv = q.inv2;
+            f.R = R;
+            f.step = seed;
+            f.stream = (unsigned)(b * 8 + 3 + 2 * i);
+            f.thr = dropout_threshold(rt.tb);
+            f.scale = rt.tb > 0.f ? 1.0f / (1.0f - rt.tb) : 1.0f;
+            T_TRY(t_ffn_fwd(f, c.st));
         }
-        T_TRY(t_gemm(ga(q.u, 256, c.w(w.f2k), 64, c.w(w.f2b), q.f2, 64, 0, R, 256, 64), false, c.st));
-        T_TRY(t_dropout(q.f2, R, 64, 64, 0, seed, b * 8 + 3 + 2 * i, rt.tb, c.st));
-        T_TRY(t_ln_fwd(q.h, q.f2, c.w(w.ln2g), c.w(w.ln2b), xout, q.xh2, q.inv2, R, c.st));
     }
     T_TRY(t_pool_fwd(a.xout, c.w(p.poolk), c.w(p.poolb), t->concat, kConcat, b * 64, a.pa, a.palpha, B, wl, c.st));
     return DPTM_OK;
@@ -378,18 +398,27 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
     for (int i = 1; i >= 0; --i) {
         TbAct& q = a.tb[i];
         const TbP& w = p.tb[i];
-        // LayerNorm 2: dsum = d(h + f2)
-        T_TRY(t_ln_bwd(dx, q.xh2, q.inv2, c.w(w.ln2g), dsum, c.g(w.ln2g), c.g(w.ln2b), R, c.st));
-        // f2 branch: dropout, ffn2, swish, ffn1
-        T_TRY(t_dropout(tmp, R, 64, 64, 0, seed, b * 8 + 3 + 2 * i, rt.tb, c.st, dsum));
-        T_TRY(t_gemm_tn(gt(q.u, 256, 0, tmp, 64, 0, c.g(w.f2k), 64, c.g(w.f2b), R, 256, 64), c.st));
-        T_TRY(t_gemm(ga(tmp, 64, c.w(w.f2k), 64, nullptr, c.s->g256, 256, 0, R, 64, 256), true, c.st));       // dU
-        T_TRY(t_swish_bwd(q.f1, c.s->g256, c.s->g256, R * 256, c.st));                                           // dF1
-        T_TRY(t_gemm_tn(gt(q.h, 64, 0, c.s->g256, 256, 0, c.g(w.f1k), 256, c.g(w.f1b), R, 64, 256), c.st));
+        // LayerNorm 2, dropout and the feed-forward layers backward in one launch: dx = d(block output) -> dh = d(h)
         {
-            GemmArgs gh = ga(c.s->g256, 256, c.w(w.f1k), 256, nullptr, dh, 64, 0, R, 256, 64);      // dH = dsum + dF1 W1^T
-            gh.residual = dsum; gh.ldr = 64;
-            T_TRY(t_gemm(gh, true, c.st));
+            const TbImg& im = t->tbimg[b][i];
+            FfnBwdArgs f;
+            f.dout = dx;
+            f.xhat = reinterpret_cast<const f32x4_tr*>(q.xh2);
+            f.inv = q.inv2;
+            f.h = q.h;
+            f.w1p = reinterpret_cast<const f32x4_tr*>(t->P + im.w1p);
+            f.w2tp = reinterpret_cast<const f32x4_tr*>(t->P + im.w2tp);
+            f.w1tp = reinterpret_cast<const f32x4_tr*>(t->P + im.w1tp);
+            f.b1 = c.w(w.f1b); f.gamma = c.w(w.ln2g);
+            f.dh = dh;
+            f.part = c.s->part;
+            f.R = R;
+            f.step = seed;
+            f.stream = (unsigned)(b * 8 + 3 + 2 * i);
+            f.thr = dropout_threshold(rt.tb);
+            f.scale = rt.tb > 0.f ? 1.0f / (1.0f - rt.tb) : 1.0f;
+            const FfnGrads fg{c.g(w.f1k), c.g(w.f1b), c.g(w.f2k), c.g(w.f2b), c.g(w.ln2g), c.g(w.ln2b)};
+            T_TRY(t_ffn_bwd(f, fg, c.st));
         }
         // LayerNorm 1: dsum = d(x + ao)
         T_TRY(t_ln_bwd(dh, q.xh1, q.inv1, c.w(w.ln1g), dsum, c.g(w.ln1g), c.g(w.ln1b), R, c.st));
@@ -480,7 +509,7 @@ void dptm_trainer_destroy(dptm_trainer* t) {
         for (int b = 0; b < 3; ++b)
             if (t->ev_join[ph][b]) (void)hipEventDestroy(t->ev_join[ph][b]);
     }
-    void* bufs[] = {t->W, t->G, t->M, t->V, t->trainable, t->arena.base, t->d_step};
+    void* bufs[] = {t->W, t->G, t->M, t->V, t->trainable, t->arena.base, t->d_step, t->P, t->pack_jobs};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (t->stream) (void)hipStreamDestroy(t->stream);
@@ -532,6 +561,36 @@ int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spe
         hipMemcpy(t->trainable, tr.data(), tr.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(t->G, 0, pb) != hipSuccess || hipMemset(t->M, 0, pb) != hipSuccess || hipMemset(t->V, 0, pb) != hipSuccess)
         return bail(DPTM_EHIP, "dptm_trainer_create: parameter upload");
+    {
+        std::vector<PackJob> jobs;
+        int64_t off = 0;
+        auto image = [&](int tensor, int K, int N, bool transpose) {
+            const int64_t at = off;
+            jobs.push_back(PackJob{t->W + t->pm.t[tensor].off, nullptr, K, N, transpose ? 1 : 0});
+            off += (int64_t)K * N;
+            return at;
+        };
+        for (int b = 0; b < 3; ++b)
+            for (int i = 0; i < 2; ++i) {
+                const TbP& q = t->pm.br[b].tb[i];
+                TbImg& im = t->tbimg[b][i];
+                im.w1p = image(q.f1k, kD, kFF, false);      // W1 [64][256]
+                im.w2p = image(q.f2k, kFF, kD, false);      // W2 [256][64]
+                im.w2tp = image(q.f2k, kD, kFF, true);      // W2^T as a [64][256] matrix
+                im.w1tp = image(q.f1k, kFF, kD, true);      // W1^T as a [256][64] matrix
+            }
+        if (hipMalloc((void**)&t->P, (size_t)off * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&t->pack_jobs, jobs.size() * sizeof(PackJob)) != hipSuccess)
+            return bail(DPTM_ENOMEM, "dptm_trainer_create: weight images");
+        int64_t at = 0;
+        for (PackJob& jb : jobs) {
+            jb.dst = t->P + at;
+            at += (int64_t)jb.K * jb.N;
+        }
+        if (hipMemcpy(t->pack_jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(DPTM_EHIP, "dptm_trainer_create: weight image table");
+        t->n_pack_jobs = (int)jobs.size();
+    }
     t->arena.cap = arena_bytes(max_batch);
     if (hipMalloc((void**)&t->arena.base, t->arena.cap) != hipSuccess) return bail(DPTM_ENOMEM, "dptm_trainer_create: activation arena");
     int rc = alloc_acts(t);
@@ -565,6 +624,7 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
     const int64_t B = n;
     int rc;
     T_TRY(hipMemsetAsync(t->G, 0, (size_t)pm.total * sizeof(float), st));
+    T_TRY(t_pack(t->pack_jobs, t->n_pack_jobs, st));          // weight images of this step's weights
     T_TRY(hipMemsetAsync(t->d_loss, 0, 64 * sizeof(float), st));
     T_TRY(hipMemsetAsync(t->bn_slots, 0, (size_t)2 * kBnLayers * 1024 * sizeof(float), st));
     // ---------------- forward: the three sequence branches on side streams, the per-site layers on `st`

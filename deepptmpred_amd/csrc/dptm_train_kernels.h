@@ -101,4 +101,59 @@ hipError_t t_l2(const float* w, float* g, int64_t n, float lambda, float* loss, 
 hipError_t t_adamw(float* w, const float* g, float* m, float* v, const uint8_t* trainable, float stat_scale, int64_t n,
                    float lr_t, float wd, float b1, float b2, float eps, float gscale, hipStream_t st);
 
+
+// ---- fused row-wise kernels (dptm_train_fused.hip)
+typedef float f32x4_tr __attribute__((ext_vector_type(4)));
+
+// one weight image in MFMA fragment order (dptm_layout.h) of the logical matrix M [K][N]:
+// M = src (raw [K][N]) or, with transpose, M[k][n] = src[n][k] (raw [N][K])
+struct PackJob {
+    const float* src;
+    float* dst;
+    int K, N, transpose;
+};
+hipError_t t_pack(const PackJob* jobs_dev, int n_jobs, hipStream_t st);
+
+// out = LayerNorm(h + dropout(W2 swish(W1 h + b1) + b2)) for R rows of 64 features
+struct FfnFwdArgs {
+    const float* h;            // [R][64] row-major
+    const f32x4_tr* w1p;       // image of W1 (K 64, N 256)
+    const f32x4_tr* w2p;       // image of W2 (K 256, N 64)
+    const float *b1, *b2, *gamma, *beta;
+    float* out;                // [R][64] row-major
+    f32x4_tr* xhat;            // [ceil(R/32)][8][64] float4: normalised rows, 32-row tiles in chain layout
+    float* inv;                // [R] 1/sigma of the LayerNorm
+    int64_t R;
+    const unsigned* step;      // per-step scalars (dropout seed)
+    unsigned stream, thr;      // dropout stream id and keep threshold (0: no dropout)
+    float scale;               // 1 / (1 - rate)
+};
+hipError_t t_ffn_fwd(const FfnFwdArgs& a, hipStream_t st);
+
+constexpr int kFfnPartStride = 33280;   // floats per workgroup of partial gradients (33,216 used)
+struct FfnBwdArgs {
+    const float* dout;         // [R][64] gradient w.r.t. the block output
+    const f32x4_tr* xhat;      // as written by the forward kernel
+    const float* inv;
+    const float* h;            // [R][64] the forward input
+    const f32x4_tr* w1p;       // image of W1 (K 64, N 256)
+    const f32x4_tr* w2tp;      // image of W2^T (K 64, N 256)
+    const f32x4_tr* w1tp;      // image of W1^T (K 256, N 64)
+    const float *b1, *gamma;
+    float* dh;                 // [R][64] gradient w.r.t. h
+    float* part;               // [t_ffn_bwd_max_parts()][kFfnPartStride] scratch for partial gradients
+    int64_t R;
+    const unsigned* step;
+    unsigned stream, thr;
+    float scale;
+};
+struct FfnGrads { float *dw1, *db1, *dw2, *db2, *dgamma, *dbeta; };   // gradient tensors (raw layouts), added to
+struct PartSegs {
+    int n, total;
+    int src[8];
+    float* dst[7];
+};
+hipError_t t_ffn_bwd(const FfnBwdArgs& a, const FfnGrads& g, hipStream_t st);
+int t_ffn_bwd_max_parts();
+
 }  // namespace dptm

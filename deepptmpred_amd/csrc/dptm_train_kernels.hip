@@ -12,6 +12,7 @@
 //   tgemm_tn   dW += shift(X)^T * dY       weight gradients (+ bias gradient)
 #include <hip/hip_runtime.h>
 
+#include "dptm_train_device.h"
 #include "dptm_train_kernels.h"
 
 namespace dptm {
@@ -23,14 +24,6 @@ __device__ __forceinline__ void mfma2(f32x16& acc, float a, float b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-
-// stateless dropout stream: lowbias32 of the element index mixed with (seed, stream)
-__device__ __forceinline__ unsigned hash_u32(unsigned seed, unsigned stream, unsigned idx) {
-    unsigned x = idx ^ (seed * 0x9E3779B9u);
-    x += stream * 0x85EBCA6Bu;
-    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-    return x;
-}
 
 // row r of a [samples*wlen] stack shifted by s stays inside its own window?
 __device__ __forceinline__ bool row_ok(int64_t r, int s, int64_t m, int wlen) {
@@ -139,12 +132,6 @@ __global__ __launch_bounds__(256) void tgemm_kernel(GemmArgs p) {
 // grid = (workgroups, cols/64), block 512 = 8 wavefronts, dynamic LDS = taps*k*256 + 8*32*68*4 bytes.
 // ------------------------------------------------------------------------------------
 constexpr int kStageStride = 68;   // floats per staged row: row-per-lane ds_read_b128 is conflict-free
-
-__device__ __forceinline__ void wave_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 template <bool NT>
 __global__ __launch_bounds__(512) void tgemm_lds_kernel(GemmArgs p) {
@@ -1196,8 +1183,7 @@ hipError_t t_dropout(float* x, int64_t rows, int cols, int64_t ld, int wlen_spat
         if (ld == cols) return hipMemcpyAsync(x, src, (size_t)rows * cols * sizeof(float), hipMemcpyDeviceToDevice, st);
         return hipMemcpy2DAsync(x, ld * sizeof(float), src, ld * sizeof(float), cols * sizeof(float), rows, hipMemcpyDeviceToDevice, st);
     }
-    double t = (double)rate * 4294967296.0;
-    const unsigned thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
+    const unsigned thr = dropout_threshold(rate);
     const float* in = src ? src : x;
     if (cols % 4 == 0 && ld % 4 == 0 && rows * cols < (int64_t)1 << 31 && rows * ld < (int64_t)1 << 31 &&
         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(in)) & 15) == 0) {
