@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dptm_layout.h"
+#include "dptm_attend.h"
 #include "dptm_mfma.h"
 #include "dptm_phase.h"
 #include "dptm_kernels.h"
@@ -23,118 +24,6 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// value held by the neighbouring lane (lane ^ 1): a quad permutation [1,0,3,2] on the DPP path
-__device__ __forceinline__ float lane_xor1(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
-}
-
-// Softmax attention of NR query rows of one site against that site's W keys for one head
-// (model.py:62-71; q arrives scaled by log2(e)/sqrt(16), so exponentials are base 2).  kp / vp: first key / value row of
-// the site in LDS at this head's 16 features.  Keys are walked in three chunks of W/3 with a
-// running maximum (the usual rescaling form of softmax), which keeps only W/3 scores live per
-// row; every K / V fragment read serves all NR rows.
-template <int W, int NR>
-__device__ __forceinline__ void attend(const float* kp, const float* vp, const float (&q)[NR][16],
-                                       float (&o)[NR][16]) {
-    constexpr int CH = W / 3;
-    static_assert(CH * 3 == W, "window sizes are multiples of 3");
-    float m[NR], den[NR];
-    f32x4 acc[NR][4];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        m[r] = -3.0e38f;
-        den[r] = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll 1
-    for (int c = 0; c < 3; ++c) {
-        float sc[NR][CH];
-        float cm[NR];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) cm[r] = -3.0e38f;
-        // K / V fragments are requested one key ahead of the products that consume them (two register
-        // sets); the sched_barrier keeps the compiler from sinking the request back to its use
-        f32x4 kb[2][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) kb[0][i] = *reinterpret_cast<const f32x4*>(kp + 4 * i);
-#pragma unroll
-        for (int t = 0; t < CH; ++t) {
-            if (t + 1 < CH) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    kb[(t + 1) & 1][i] = *reinterpret_cast<const f32x4*>(kp + (t + 1) * kLdsStride + 4 * i);
-            }
-            const f32x4 (&k)[4] = kb[t & 1];
-            // two partial sums per row so that the 16 products go through 8 packed FMAs; the rows'
-            // chains are written interleaved so that consecutive instructions are independent
-            f32x2 a2[NR];
-#pragma unroll
-            for (int r = 0; r < NR; ++r) a2[r] = f32x2{0.f, 0.f};
-#pragma unroll
-            for (int e = 0; e < 4; e += 2)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int r = 0; r < NR; ++r)
-                        a2[r] += f32x2{q[r][4 * i + e], q[r][4 * i + e + 1]} * f32x2{k[i][e], k[i][e + 1]};
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const float a = a2[r][0] + a2[r][1];
-                sc[r][t] = a;
-                cm[r] = fmaxf(cm[r], a);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        f32x4 vb[2][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) vb[0][i] = *reinterpret_cast<const f32x4*>(vp + 4 * i);
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const float mn = fmaxf(m[r], cm[r]);
-            const float alpha = __builtin_amdgcn_exp2f(m[r] - mn);
-            m[r] = mn;
-            den[r] *= alpha;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[r][i] *= alpha;
-        }
-        // all exponentials of the chunk first (independent of each other, so the quarter-rate unit
-        // pipelines them), then the weighted sum
-#pragma unroll
-        for (int t = 0; t < CH; ++t)
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                sc[r][t] = __builtin_amdgcn_exp2f(sc[r][t] - m[r]);
-                den[r] += sc[r][t];
-            }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < CH; ++t) {
-            if (t + 1 < CH) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    vb[(t + 1) & 1][i] = *reinterpret_cast<const f32x4*>(vp + (t + 1) * kLdsStride + 4 * i);
-            }
-            const f32x4 (&v)[4] = vb[t & 1];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < NR; ++r) acc[r][i] += sc[r][t] * v[i];
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        kp += CH * kLdsStride;
-        vp += CH * kLdsStride;
-    }
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const float rden = 1.0f / den[r];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[r][4 * i + e] = acc[r][i][e] * rden;
-    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -368,17 +257,18 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
             const float* kp0 = bufA + att_start * kLdsStride + head_off;
             const float* kp1 = bufA + att_start_pair * kLdsStride + head_off;
             const int v_off = kTileRows * kLdsStride;       // bufB = bufA + v_off
+            float sm[2], sr[2];                             // softmax statistics: not needed for scoring
             if (__builtin_amdgcn_ballot_w64(att_start != att_start_pair) == 0) {
-                attend<W, 2>(kp0, kp0 + v_off, q, o);
+                attend<W, 2>(kp0, kp0 + v_off, q, o, sm, sr);
             } else {
                 // a pair in this wavefront straddles two sites: the rows walk their own keys
-                float q1[1][16], o1[1][16];
+                float q1[1][16], o1[1][16], sm1[1], sr1[1];
 #pragma unroll
                 for (int d = 0; d < 16; ++d) q1[0][d] = q[0][d];
-                attend<W, 1>(kp0, kp0 + v_off, q1, o1);
+                attend<W, 1>(kp0, kp0 + v_off, q1, o1, sm1, sr1);
 #pragma unroll
                 for (int d = 0; d < 16; ++d) { o[0][d] = o1[0][d]; q1[0][d] = q[1][d]; }
-                attend<W, 1>(kp1, kp1 + v_off, q1, o1);
+                attend<W, 1>(kp1, kp1 + v_off, q1, o1, sm1, sr1);
 #pragma unroll
                 for (int d = 0; d < 16; ++d) o[1][d] = o1[0][d];
             }

@@ -102,14 +102,11 @@ struct Arena {
     }
 };
 
-struct TbAct { float *x, *q, *k, *v, *prob, *o, *ao, *xh1, *inv1, *h, *xh2, *inv2; };
-// weight images of one TransformerBlock for the fused kernels (floats into dptm_trainer::P)
-struct TbImg { int64_t w1p, w2p, w2tp, w1tp; };
 struct BranchAct {
     int wlen;
     float *x0, *s, *a1, *y1, *z1, *a2, *y2, *x1, *mi1, *mi2;   // mi = mean|inv of a BatchNorm
-    TbAct tb[2];
-    float *xout, *pa, *palpha;
+    TbSave sv[2];                      // what the fused TransformerBlock kernels keep for the backward pass
+    f32x2_tr* pool;                    // per row: tanh score and pooling weight
 };
 
 }  // namespace
@@ -123,7 +120,7 @@ struct dptm_trainer {
     float* P = nullptr;                   // weight images in MFMA fragment order, rebuilt from W every step
     PackJob* pack_jobs = nullptr;         // device table of the images to build
     int n_pack_jobs = 0;
-    TbImg tbimg[3][2];
+    int64_t img_fwd[3], img_bwd[3];       // per branch: packed forward image (dptm_layout.h) and transposed images, floats into P
     uint8_t* trainable = nullptr;
     Arena arena;
     BranchAct ba[3];
@@ -135,9 +132,8 @@ struct dptm_trainer {
     // Scratch of one concurrent lane of the step: the three sequence branches run on side streams next to
     // the per-site layers, so each owns its gradient scratch ([rows][64] / [rows][256]) and BatchNorm sums.
     struct Scratch {
-        float *g64a = nullptr, *g64b = nullptr, *g64c = nullptr, *g64d = nullptr, *g256 = nullptr;
-        float *gq = nullptr, *gk = nullptr, *gv = nullptr, *bnsums_all = nullptr;
-        float* part = nullptr;            // partial parameter gradients of the fused backward kernels
+        float *g64a = nullptr, *g64b = nullptr, *g64c = nullptr, *g64d = nullptr, *bnsums_all = nullptr;
+        float* part = nullptr;            // partial parameter gradients of the fused backward kernel, one slab per workgroup
     };
     Scratch sc[4];                        // [0..2] sequence branches, [3] per-site layers (BatchNorm sums only)
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
@@ -185,14 +181,22 @@ int alloc_acts(dptm_trainer* t) {
         const size_t R = (size_t)B * kW[b], R64 = R * 64;
         ok &= need(a.x0, R64) && need(a.s, R64) && need(a.a1, R64) && need(a.y1, R64) && need(a.z1, R64) &&
               need(a.a2, R64) && need(a.y2, R64) && need(a.x1, R64) && need(a.mi1, 128) && need(a.mi2, 128);
+        // chain-tiled arrays cover the padded rows of the largest tiling a batch up to max_batch can take
+        const size_t RP = (size_t)t_tile_rows_max(B, kW[b]);
+        auto need4 = [&](f32x4_tr*& p4, size_t rows) -> bool { float* f = nullptr; const bool k = need(f, rows * 64); p4 = reinterpret_cast<f32x4_tr*>(f); return k; };
         for (int i = 0; i < 2; ++i) {
-            TbAct& q = a.tb[i];
-            ok &= need(q.q, R64) && need(q.k, R64) && need(q.v, R64) && need(q.prob, (size_t)B * 4 * kW[b] * kW[b]) &&
-                  need(q.o, R64) && need(q.ao, R64) && need(q.xh1, R64) && need(q.inv1, R) && need(q.h, R64) &&
-                  need(q.xh2, (R + 31) / 32 * 2048) && need(q.inv2, R);
+            TbSave& q = a.sv[i];
+            float *st = nullptr, *iv = nullptr;
+            ok &= need4(q.q, RP) && need4(q.k, RP) && need4(q.v, RP) && need4(q.o, RP) && need4(q.xh1, RP) && need4(q.xh2, RP) &&
+                  need(st, RP * 2 * 4) && need(iv, RP * 2 * 2);
+            q.stat = reinterpret_cast<f32x4_tr*>(st);
+            q.inv = reinterpret_cast<f32x2_tr*>(iv);
         }
-        ok &= need(a.tb[1].x, R64) && need(a.xout, R64) && need(a.pa, R) && need(a.palpha, R);
-        a.tb[0].x = a.x1;
+        {
+            float* pl = nullptr;
+            ok &= need(pl, RP * 2 * 2);
+            a.pool = reinterpret_cast<f32x2_tr*>(pl);
+        }
     }
     ok &= need(t->sa, B * 128) && need(t->sy, B * 128) && need(t->smi, 256) && need(t->ea, B * 512) && need(t->ey, B * 512) &&
           need(t->emi, 1024) && need(t->e1, B * 512) && need(t->e2a, B * 256) && need(t->concat, B * 576) &&
@@ -205,8 +209,7 @@ int alloc_acts(dptm_trainer* t) {
         if (b == 3) break;
         const size_t RM = (size_t)B * kW[b];
         ok &= need(s.g64a, RM * 64) && need(s.g64b, RM * 64) && need(s.g64c, RM * 64) && need(s.g64d, RM * 64) &&
-              need(s.gq, RM * 64) && need(s.gk, RM * 64) && need(s.gv, RM * 64) &&
-              need(s.part, (size_t)t_ffn_bwd_max_parts() * kFfnPartStride);
+              need(s.part, (size_t)kTbMaxParts * kTbPartStride);
     }
     ok &= need(t->dconcat, B * 576) && need(t->d512a, B * 512) && need(t->d512b, B * 512) && need(t->d256a, B * 256) &&
           need(t->d256b, B * 256) && need(t->d128, B * 128);
@@ -216,12 +219,13 @@ int alloc_acts(dptm_trainer* t) {
 size_t arena_bytes(int64_t B) {
     size_t f = 0;
     for (int b = 0; b < 3; ++b) {
-        const size_t R = (size_t)B * kW[b];
-        f += R * 64 * 9 + 2 * (R * 64 * 9 + (R + 32) * 64 + R * 2 + (size_t)B * 4 * kW[b] * kW[b]) + R * 64 + R * 2;
-        f += (size_t)t_ffn_bwd_max_parts() * kFfnPartStride;
+        const size_t R = (size_t)B * kW[b], RP = (size_t)t_tile_rows_max(B, kW[b]);
+        f += R * 64 * 8 + 2 * 128;                                  // conv block activations
+        f += 2 * (RP * 64 * 6 + RP * 8 + RP * 4) + RP * 4;          // saved TransformerBlock activations, pooling
+        f += R * 64 * 4 + (size_t)kTbMaxParts * kTbPartStride;      // gradient scratch, partial gradients
     }
     f += (size_t)B * (128 * 2 + 512 * 3 + 256 + 576 + 512 * 3 + 256 * 3 + 2);
-    f += (size_t)B * (21 + 33 + 51) * (64 * 7) + (4 + 2 * 10) * 1024 + (size_t)B * (576 + 1024 + 512 + 128);
+    f += (4 + 2 * 10) * 1024 + 64 + (size_t)B * (576 + 1024 + 512 + 128);
     return f * sizeof(float) + (size_t)640 * 256 + (1 << 20);   // + per-allocation rounding slack
 }
 
@@ -338,47 +342,27 @@ int branch_fwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
     if ((rc = conv_fwd(c, a.z1, p.c3bk, p.c3bb, 3, a.a2, R, wl, a.y2))) return rc;
     if ((rc = bn_train_fwd(c, a.y2, a.x1, 64, 0, R, 64, p.bn2, a.mi2))) return rc;
     T_TRY(t_add(a.x1, a.s, R64, c.st));
-    for (int i = 0; i < 2; ++i) {
-        TbAct& q = a.tb[i];
-        const TbP& w = p.tb[i];
-        float* xout = i == 0 ? a.tb[1].x : a.xout;
-        {
-            // Q, K, V: three products of the same rows, one launch when kernels, biases and outputs are evenly spaced
-            const int64_t ws = c.w(w.wk) - c.w(w.wq), bs = c.w(w.bk) - c.w(w.bq), os = q.k - q.q;
-            if (c.w(w.wv) - c.w(w.wk) == ws && c.w(w.bv) - c.w(w.bk) == bs && q.v - q.k == os) {
-                GemmArgs g3 = ga(q.x, 64, c.w(w.wq), 64, c.w(w.bq), q.q, 64, 0, R, 64, 64);
-                g3.batch = 3; g3.bx = 0; g3.bw = ws; g3.bb = bs; g3.bo = os;
-                T_TRY(t_gemm(g3, false, c.st));
-            } else {
-                T_TRY(t_gemm(ga(q.x, 64, c.w(w.wq), 64, c.w(w.bq), q.q, 64, 0, R, 64, 64), false, c.st));
-                T_TRY(t_gemm(ga(q.x, 64, c.w(w.wk), 64, c.w(w.bk), q.k, 64, 0, R, 64, 64), false, c.st));
-                T_TRY(t_gemm(ga(q.x, 64, c.w(w.wv), 64, c.w(w.bv), q.v, 64, 0, R, 64, 64), false, c.st));
-            }
-        }
-        T_TRY(t_attn_fwd(q.q, q.k, q.v, q.o, q.prob, B, wl, c.st));
-        T_TRY(t_gemm(ga(q.o, 64, c.w(w.wo), 64, c.w(w.bo), q.ao, 64, 0, R, 64, 64), false, c.st));
-        T_TRY(t_dropout(q.ao, R, 64, 64, 0, seed, b * 8 + 2 + 2 * i, rt.tb, c.st));
-        T_TRY(t_ln_fwd(q.x, q.ao, c.w(w.ln1g), c.w(w.ln1b), q.h, q.xh1, q.inv1, R, c.st));
-        {
-            // feed-forward half in one launch: out = LN2(h + dropout(W2 swish(W1 h + b1) + b2))
-            const TbImg& im = t->tbimg[b][i];
-            FfnFwdArgs f;
-            f.h = q.h;
-            f.w1p = reinterpret_cast<const f32x4_tr*>(t->P + im.w1p);
-            f.w2p = reinterpret_cast<const f32x4_tr*>(t->P + im.w2p);
-            f.b1 = c.w(w.f1b); f.b2 = c.w(w.f2b); f.gamma = c.w(w.ln2g); f.beta = c.w(w.ln2b);
-            f.out = xout;
-            f.xhat = reinterpret_cast<f32x4_tr*>(q.xh2);
-            f.inv = q.inv2;
-            f.R = R;
-            f.step = seed;
-            f.stream = (unsigned)(b * 8 + 3 + 2 * i);
-            f.thr = dropout_threshold(rt.tb);
-            f.scale = rt.tb > 0.f ? 1.0f / (1.0f - rt.tb) : 1.0f;
-            T_TRY(t_ffn_fwd(f, c.st));
-        }
+    {
+        // both TransformerBlocks and the attention pooling in one launch (model.py:172-182)
+        const TileCfg tc = t_tile_cfg(B, wl);
+        TbFwdArgs f;
+        f.P = reinterpret_cast<const f32x4_tr*>(t->P + t->img_fwd[b]);
+        f.x1 = a.x1;
+        f.sv[0] = a.sv[0];
+        f.sv[1] = a.sv[1];
+        f.pool = a.pool;
+        f.out = t->concat;
+        f.ldo = kConcat;
+        f.col_off = b * 64;
+        f.n_sites = B;
+        f.S = tc.S;
+        f.ntiles = tc.ntiles;
+        f.step = seed;
+        f.stream_base = (unsigned)(b * 8 + 2);
+        f.thr = dropout_threshold(rt.tb);
+        f.scale = rt.tb > 0.f ? 1.0f / (1.0f - rt.tb) : 1.0f;
+        T_TRY(t_tb_fwd(f, wl, tc.NW, c.st));
     }
-    T_TRY(t_pool_fwd(a.xout, c.w(p.poolk), c.w(p.poolb), t->concat, kConcat, b * 64, a.pa, a.palpha, B, wl, c.st));
     return DPTM_OK;
 }
 
@@ -394,67 +378,39 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
     float* dsum = c.s->g64b;
     float* tmp = c.s->g64c;
     float* dh = c.s->g64d;
-    T_TRY(t_pool_bwd(a.xout, c.w(p.poolk), t->dconcat, kConcat, b * 64, a.pa, a.palpha, dx, c.g(p.poolk), c.g(p.poolb), B, wl, c.st));
-    for (int i = 1; i >= 0; --i) {
-        TbAct& q = a.tb[i];
-        const TbP& w = p.tb[i];
-        // LayerNorm 2, dropout and the feed-forward layers backward in one launch: dx = d(block output) -> dh = d(h)
-        {
-            const TbImg& im = t->tbimg[b][i];
-            FfnBwdArgs f;
-            f.dout = dx;
-            f.xhat = reinterpret_cast<const f32x4_tr*>(q.xh2);
-            f.inv = q.inv2;
-            f.h = q.h;
-            f.w1p = reinterpret_cast<const f32x4_tr*>(t->P + im.w1p);
-            f.w2tp = reinterpret_cast<const f32x4_tr*>(t->P + im.w2tp);
-            f.w1tp = reinterpret_cast<const f32x4_tr*>(t->P + im.w1tp);
-            f.b1 = c.w(w.f1b); f.gamma = c.w(w.ln2g);
-            f.dh = dh;
-            f.part = c.s->part;
-            f.R = R;
-            f.step = seed;
-            f.stream = (unsigned)(b * 8 + 3 + 2 * i);
-            f.thr = dropout_threshold(rt.tb);
-            f.scale = rt.tb > 0.f ? 1.0f / (1.0f - rt.tb) : 1.0f;
-            const FfnGrads fg{c.g(w.f1k), c.g(w.f1b), c.g(w.f2k), c.g(w.f2b), c.g(w.ln2g), c.g(w.ln2b)};
-            T_TRY(t_ffn_bwd(f, fg, c.st));
+    {
+        // pooling and both TransformerBlocks backward in one launch: d(concat columns of this branch) -> dx = d(x1)
+        const TileCfg tc = t_tile_cfg(B, wl);
+        TbBwdArgs f;
+        f.P = reinterpret_cast<const f32x4_tr*>(t->P + t->img_fwd[b]);
+        f.PT = reinterpret_cast<const f32x4_tr*>(t->P + t->img_bwd[b]);
+        f.x1 = a.x1;
+        f.sv[0] = a.sv[0];
+        f.sv[1] = a.sv[1];
+        f.pool = a.pool;
+        f.dout = t->dconcat;
+        f.ldd = kConcat;
+        f.col_off = b * 64;
+        f.dx1 = dx;
+        f.part = c.s->part;
+        f.n_sites = B;
+        f.S = tc.S;
+        f.ntiles = tc.ntiles;
+        f.step = seed;
+        f.stream_base = (unsigned)(b * 8 + 2);
+        f.thr = dropout_threshold(rt.tb);
+        f.scale = rt.tb > 0.f ? 1.0f / (1.0f - rt.tb) : 1.0f;
+        TbGrads g;
+        for (int i = 0; i < 2; ++i) {
+            const TbP& w = p.tb[i];
+            g.wq[i] = c.g(w.wq); g.bq[i] = c.g(w.bq); g.wk[i] = c.g(w.wk); g.bk[i] = c.g(w.bk);
+            g.wv[i] = c.g(w.wv); g.bv[i] = c.g(w.bv); g.wo[i] = c.g(w.wo); g.bo[i] = c.g(w.bo);
+            g.w1[i] = c.g(w.f1k); g.b1[i] = c.g(w.f1b); g.w2[i] = c.g(w.f2k); g.b2[i] = c.g(w.f2b);
+            g.ln1g[i] = c.g(w.ln1g); g.ln1b[i] = c.g(w.ln1b); g.ln2g[i] = c.g(w.ln2g); g.ln2b[i] = c.g(w.ln2b);
         }
-        // LayerNorm 1: dsum = d(x + ao)
-        T_TRY(t_ln_bwd(dh, q.xh1, q.inv1, c.w(w.ln1g), dsum, c.g(w.ln1g), c.g(w.ln1b), R, c.st));
-        T_TRY(t_dropout(tmp, R, 64, 64, 0, seed, b * 8 + 2 + 2 * i, rt.tb, c.st, dsum));                     // dAO
-        T_TRY(t_gemm_tn(gt(q.o, 64, 0, tmp, 64, 0, c.g(w.wo), 64, c.g(w.bo), R, 64, 64), c.st));
-        T_TRY(t_gemm(ga(tmp, 64, c.w(w.wo), 64, nullptr, dh, 64, 0, R, 64, 64), true, c.st));                // dO (in dh)
-        T_TRY(t_attn_bwd(q.q, q.k, q.v, q.prob, dh, c.s->gq, c.s->gk, c.s->gv, B, wl, c.st));
-        {
-            const int64_t ys = c.s->gk - c.s->gq, ws = c.g(w.wk) - c.g(w.wq), bs = c.g(w.bk) - c.g(w.bq);
-            if (c.s->gv - c.s->gk == ys && c.g(w.wv) - c.g(w.wk) == ws && c.g(w.bv) - c.g(w.bk) == bs) {
-                GemmTnArgs g3 = gt(q.x, 64, 0, c.s->gq, 64, 0, c.g(w.wq), 64, c.g(w.bq), R, 64, 64);
-                g3.batch = 3; g3.bx = 0; g3.bdy = ys; g3.bdw = ws; g3.bdb = bs;
-                T_TRY(t_gemm_tn(g3, c.st));
-            } else {
-                T_TRY(t_gemm_tn(gt(q.x, 64, 0, c.s->gq, 64, 0, c.g(w.wq), 64, c.g(w.bq), R, 64, 64), c.st));
-                T_TRY(t_gemm_tn(gt(q.x, 64, 0, c.s->gk, 64, 0, c.g(w.wk), 64, c.g(w.bk), R, 64, 64), c.st));
-                T_TRY(t_gemm_tn(gt(q.x, 64, 0, c.s->gv, 64, 0, c.g(w.wv), 64, c.g(w.bv), R, 64, 64), c.st));
-            }
-        }
-        // dX = dsum + dQ Wq^T + dK Wk^T + dV Wv^T   (written into dx)
-        {
-            // one pass when the three gradient arrays and the three kernels are evenly spaced in their buffers
-            const int64_t xs = c.s->gk - c.s->gq, ws = c.w(w.wk) - c.w(w.wq);
-            if (c.s->gv - c.s->gk == xs && c.w(w.wv) - c.w(w.wk) == ws && xs > 0 && ws > 0) {
-                GemmArgs gx3 = ga(c.s->gq, 64, c.w(w.wq), 64, nullptr, dx, 64, 0, R, 64, 64);
-                gx3.taps = 3; gx3.tap_dir = 0; gx3.tap_stride = ws; gx3.x_tap_stride = xs;
-                gx3.residual = dsum; gx3.ldr = 64;
-                T_TRY(t_gemm(gx3, true, c.st));
-            } else {
-                GemmArgs gq = ga(c.s->gq, 64, c.w(w.wq), 64, nullptr, dx, 64, 0, R, 64, 64);
-                gq.residual = dsum; gq.ldr = 64;
-                T_TRY(t_gemm(gq, true, c.st));
-                T_TRY(t_gemm(ga(c.s->gk, 64, c.w(w.wk), 64, nullptr, dx, 64, 0, R, 64, 64, 0, 0, 1), true, c.st));
-                T_TRY(t_gemm(ga(c.s->gv, 64, c.w(w.wv), 64, nullptr, dx, 64, 0, R, 64, 64, 0, 0, 1), true, c.st));
-            }
-        }
+        g.poolw = c.g(p.poolk);
+        g.poolb = c.g(p.poolb);
+        T_TRY(t_tb_bwd(f, g, wl, tc.NW, c.st));
     }
     // conv block: x1 = BN2(swish(conv3b(z1))) + conv1(x0); dx = d(x1)
     // BatchNorm 2 -> dY2 (tmp) -> dA2 (tmp)
@@ -562,31 +518,65 @@ int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spe
         hipMemset(t->G, 0, pb) != hipSuccess || hipMemset(t->M, 0, pb) != hipSuccess || hipMemset(t->V, 0, pb) != hipSuccess)
         return bail(DPTM_EHIP, "dptm_trainer_create: parameter upload");
     {
+        // per branch: the packed forward image the fused kernels read (layout of dptm_layout.h) and the transposed
+        // images of the backward pass; pack_kernel rebuilds them from W at the start of every step
         std::vector<PackJob> jobs;
-        int64_t off = 0;
-        auto image = [&](int tensor, int K, int N, bool transpose) {
+        int64_t off = 0;                       // floats into P
+        auto reserve = [&](int64_t floats) {
             const int64_t at = off;
-            jobs.push_back(PackJob{t->W + t->pm.t[tensor].off, nullptr, K, N, transpose ? 1 : 0});
-            off += (int64_t)K * N;
+            off += (floats + 63) / 64 * 64;
             return at;
         };
-        for (int b = 0; b < 3; ++b)
-            for (int i = 0; i < 2; ++i) {
-                const TbP& q = t->pm.br[b].tb[i];
-                TbImg& im = t->tbimg[b][i];
-                im.w1p = image(q.f1k, kD, kFF, false);      // W1 [64][256]
-                im.w2p = image(q.f2k, kFF, kD, false);      // W2 [256][64]
-                im.w2tp = image(q.f2k, kD, kFF, true);      // W2^T as a [64][256] matrix
-                im.w1tp = image(q.f1k, kFF, kD, true);      // W1^T as a [256][64] matrix
+        struct Pending { int tensor; int64_t src_off; int64_t dst; int kind, K, N, tr; };
+        std::vector<Pending> pend;
+        for (int b = 0; b < 3; ++b) {
+            const BranchP& q = t->pm.br[b];
+            const int64_t F = t->img_fwd[b] = reserve((int64_t)kBranchF4 * 4);
+            const int64_t T = t->img_bwd[b] = reserve((int64_t)2 * kBtSize * 4);
+            auto mat = [&](int tensor, int64_t src_off, int64_t dst_f4, int K, int N, bool tr, int64_t base) {
+                pend.push_back(Pending{tensor, src_off, base + dst_f4 * 4, 0, K, N, tr ? 1 : 0});
+            };
+            auto vec = [&](int tensor, int64_t dst_f4, int n) { pend.push_back(Pending{tensor, 0, F + dst_f4 * 4, 1, n, 0, 0}); };
+            auto copy = [&](int tensor, int64_t dst_f4, int n) { pend.push_back(Pending{tensor, 0, F + dst_f4 * 4, 2, n, 0, 0}); };
+            copy(q.emb, kOffEmb, kCodes * kD);
+            copy(q.pos, kOffPos, kW[b] * kD);
+            mat(q.sck, 0, kOffScW, kD, kD, false, F);
+            for (int tap = 0; tap < 3; ++tap) {
+                mat(q.c3ak, (int64_t)tap * kD * kD, kOffC3aW + tap * kMat64, kD, kD, false, F);
+                mat(q.c3bk, (int64_t)tap * kD * kD, kOffC3bW + tap * kMat64, kD, kD, false, F);
             }
-        if (hipMalloc((void**)&t->P, (size_t)off * sizeof(float)) != hipSuccess ||
-            hipMalloc((void**)&t->pack_jobs, jobs.size() * sizeof(PackJob)) != hipSuccess)
-            return bail(DPTM_ENOMEM, "dptm_trainer_create: weight images");
-        int64_t at = 0;
-        for (PackJob& jb : jobs) {
-            jb.dst = t->P + at;
-            at += (int64_t)jb.K * jb.N;
+            vec(q.scb, kOffConvV + kVScB * kVec64, kD);
+            vec(q.c3ab, kOffConvV + kVC3aB * kVec64, kD);
+            vec(q.c3bb, kOffConvV + kVC3bB * kVec64, kD);
+            for (int i = 0; i < 2; ++i) {
+                const TbP& w = q.tb[i];
+                const int64_t base = kOffTb + (int64_t)i * kTbSize;
+                mat(w.wq, 0, base + kTbWq, kD, kD, false, F);
+                mat(w.wk, 0, base + kTbWk, kD, kD, false, F);
+                mat(w.wv, 0, base + kTbWv, kD, kD, false, F);
+                mat(w.wo, 0, base + kTbWo, kD, kD, false, F);
+                mat(w.f1k, 0, base + kTbF1, kD, kFF, false, F);
+                mat(w.f2k, 0, base + kTbF2, kFF, kD, false, F);
+                const int vid[9] = {w.bq, w.bk, w.bv, w.bo, w.ln1g, w.ln1b, w.f2b, w.ln2g, w.ln2b};   // order of enum TbVec
+                for (int v = 0; v < 9; ++v) vec(vid[v], base + kTbVec + v * kVec64, kD);
+                vec(w.f1b, base + kTbB1, kFF);
+                const int64_t tb = (int64_t)i * kBtSize;
+                mat(w.wq, 0, tb + kBtWqT, kD, kD, true, T);
+                mat(w.wk, 0, tb + kBtWkT, kD, kD, true, T);
+                mat(w.wv, 0, tb + kBtWvT, kD, kD, true, T);
+                mat(w.wo, 0, tb + kBtWoT, kD, kD, true, T);
+                mat(w.f2k, 0, tb + kBtW2T, kD, kFF, true, T);     // W2^T: M[k][n] = W2[n][k], K = 64, N = 256
+                mat(w.f1k, 0, tb + kBtW1T, kFF, kD, true, T);     // W1^T: M[k][n] = W1[n][k], K = 256, N = 64
+            }
+            vec(q.poolk, kOffPoolV, kD);
+            copy(q.poolb, kOffPoolB, 1);
         }
+        if (hipMalloc((void**)&t->P, (size_t)off * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&t->pack_jobs, pend.size() * sizeof(PackJob)) != hipSuccess)
+            return bail(DPTM_ENOMEM, "dptm_trainer_create: weight images");
+        if (hipMemset(t->P, 0, (size_t)off * sizeof(float)) != hipSuccess) return bail(DPTM_EHIP, "dptm_trainer_create: weight images");
+        for (const Pending& q : pend)
+            jobs.push_back(PackJob{t->W + t->pm.t[q.tensor].off + q.src_off, t->P + q.dst, q.kind, q.K, q.N, q.tr});
         if (hipMemcpy(t->pack_jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice) != hipSuccess)
             return bail(DPTM_EHIP, "dptm_trainer_create: weight image table");
         t->n_pack_jobs = (int)jobs.size();

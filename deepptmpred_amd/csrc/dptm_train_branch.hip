@@ -1,0 +1,1037 @@
+// Fused sequence-branch kernels of the training step (gfx950): both TransformerBlocks and the attention
+// pooling of one branch (pred/train_PTM/model.py:44-118, 172-182) in ONE forward and ONE backward launch per
+// window size, so that the activations of a site stay in registers / LDS across the layers.
+//
+//   tb_fwd_kernel<W>   x1 -> pooled rows.  Saves per block what the backward pass cannot rebuild cheaply:
+//                      q, k, v, the attention output, the two normalised rows (xhat) with 1/sigma, and the
+//                      softmax statistics (row maximum, 1/denominator) instead of the W x W probabilities.
+//   tb_bwd_kernel<W>   d(pooled rows) -> d(x1) and the gradients of every parameter of the two blocks and the
+//                      pooling.  The FFN hidden layer and the attention probabilities are recomputed.
+//   reduce_*_kernel    sum the workgroups' partial parameter gradients into the gradient buffer.
+//   pack_kernel        rebuilds the weight images (MFMA fragment order) from the raw weights every step.
+//
+// Tiling: a workgroup owns S whole sites = S*W rows in NW wavefronts of 32 rows (dptm_layout.h "chain layout":
+// a row per lane), NW*32 >= S*W; the host picks (S, NW) from the batch size so that small batches still spread
+// over the chip.  Row-wise products run register to register on v_mfma_f32_32x32x2_f32.  A weight gradient
+// dW = X^T dY contracts over the rows, which sit on the lanes, so both operands pass through LDS images
+// [row][68]: the eight wavefronts take the four 32 x 32 blocks of a 64 x 64 unit over two row halves, and the
+// workgroup adds the result to its private partial buffer in global memory (plain read-modify-write: a
+// workgroup is the only writer of its buffer).  Attention backward runs on the vector unit in two passes,
+// lane = query row (dq) and lane = key row (dk, dv), each rebuilding p = exp2(s - max) / den.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "dptm_attend.h"
+#include "dptm_layout.h"
+#include "dptm_mfma.h"
+#include "dptm_train_device.h"
+#include "dptm_train_kernels.h"
+
+namespace dptm {
+
+// ------------------------------------------------------------------------------------ weight images
+
+// kind 0: dst[((t*(K/8) + u)*64 + lane)*4 + e] = M[8u + 4h + e][32t + j], M[k][n] = src[k*N + n] or src[n*K + k]
+// kind 1: dst[(h*(K/8) + u)*4 + e] = src[8u + 4h + e];  kind 2: dst[o] = src[o]
+__global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ jobs) {
+    const PackJob jb = jobs[blockIdx.y];
+    if (jb.kind == 0) {
+        const int total = jb.K * jb.N;
+        const int k8 = jb.K >> 3;
+        for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x) {
+            const int e = o & 3, lane = (o >> 2) & 63, tu = o >> 8;
+            const int t = tu / k8, u = tu - t * k8;
+            const int k = 8 * u + 4 * (lane >> 5) + e, n = 32 * t + (lane & 31);
+            jb.dst[o] = jb.transpose ? jb.src[(int64_t)n * jb.K + k] : jb.src[(int64_t)k * jb.N + n];
+        }
+    } else if (jb.kind == 1) {
+        const int g8 = jb.K >> 3;
+        for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < jb.K; o += gridDim.x * blockDim.x) {
+            const int e = o & 3, g = o >> 2;
+            const int h = g / g8, u = g - h * g8;
+            jb.dst[o] = jb.src[8 * u + 4 * h + e];
+        }
+    } else {
+        for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < jb.K; o += gridDim.x * blockDim.x) jb.dst[o] = jb.src[o];
+    }
+}
+
+hipError_t t_pack(const PackJob* jobs_dev, int n_jobs, hipStream_t st) {
+    if (n_jobs) hipLaunchKernelGGL(pack_kernel, dim3(8, (unsigned)n_jobs), dim3(256), 0, st, jobs_dev);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------ tiling
+
+namespace {
+struct Cand { int S, NW; };
+// candidates per window size, largest tile first; NW in {1, 2, 4, 8} so that the weight-gradient blocks divide evenly
+const Cand kCand21[] = {{12, 8}, {6, 4}, {3, 2}, {1, 1}};
+const Cand kCand33[] = {{7, 8}, {3, 4}, {1, 2}};
+const Cand kCand51[] = {{5, 8}, {2, 4}, {1, 2}};
+// take the largest tile that still gives this many workgroups (DPTM_TRAIN_MIN_TILES overrides: tests use it to
+// run the large tiles on small batches)
+int64_t min_tiles() {
+    static const int64_t v = [] {
+        const char* e = std::getenv("DPTM_TRAIN_MIN_TILES");
+        const long long x = e ? std::atoll(e) : 0;
+        return (int64_t)(x >= 1 ? x : 192);
+    }();
+    return v;
+}
+}  // namespace
+
+TileCfg t_tile_cfg(int64_t n, int wlen) {
+    const Cand* c = wlen == 21 ? kCand21 : wlen == 33 ? kCand33 : kCand51;
+    const int nc = wlen == 21 ? 4 : 3;
+    TileCfg r{c[nc - 1].S, c[nc - 1].NW, 0};
+    for (int i = 0; i < nc; ++i)
+        if ((n + c[i].S - 1) / c[i].S >= min_tiles()) {
+            r.S = c[i].S;
+            r.NW = c[i].NW;
+            break;
+        }
+    r.ntiles = (n + r.S - 1) / r.S;
+    return r;
+}
+
+int64_t t_tile_rows_max(int64_t max_sites, int wlen) {
+    // the padded row count grows with n inside one (S, NW) regime: its maximum sits at a regime's upper end
+    const Cand* c = wlen == 21 ? kCand21 : wlen == 33 ? kCand33 : kCand51;
+    const int nc = wlen == 21 ? 4 : 3;
+    int64_t best = 0;
+    for (int i = 0; i < nc; ++i) {
+        // largest n (<= max_sites) that still selects candidate i: below the threshold of every larger tile
+        int64_t hi = max_sites;
+        if (i > 0) hi = hi < (min_tiles() - 1) * c[i - 1].S ? hi : (min_tiles() - 1) * c[i - 1].S;
+        if (hi < 1) continue;
+        const TileCfg t = t_tile_cfg(hi, wlen);
+        const int64_t rows = t.ntiles * t.NW * 32;
+        best = rows > best ? rows : best;
+    }
+    return best;
+}
+
+// ------------------------------------------------------------------------------------ device helpers
+
+template <int NT>
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+}
+
+// inverse of acc_to_x: accumulator tiles that start from a chain-layout vector
+__device__ __forceinline__ void x_to_acc(const f32x4 (&x)[8], f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][4 * g + e] = x[4 * t + g][e];
+}
+
+// chain-layout row vector <-> the lane's row of an LDS image [rows][kLdsStride]
+__device__ __forceinline__ void chain_store(float* row_base, int h, const f32x4 (&x)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x4*>(row_base + 8 * u + 4 * h) = x[u];
+}
+
+// sum over 32 image rows of column `lane` (lane = feature)
+__device__ __forceinline__ float colsum32(const float* img_rows, int lane) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; r += 2) {
+        s0 += img_rows[r * kLdsStride + lane];
+        s1 += img_rows[(r + 1) * kLdsStride + lane];
+    }
+    return s0 + s1;
+}
+
+// inverted dropout of a chain-layout row vector; the element index of (row r, feature c) is r*64 + c, as in the
+// layer-wise dropout kernels and the NumPy restatement, so every implementation sees the same mask
+__device__ __forceinline__ void dropout_chain(f32x4 (&x)[8], int64_t r, int h, unsigned seed, unsigned stream, unsigned thr,
+                                              float scale) {
+    if (thr == 0u) return;
+    const unsigned base = (unsigned)(r * 64) + 4 * h;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[u][e] = hash_u32(seed, stream, base + 8 * u + e) >= thr ? x[u][e] * scale : 0.f;
+}
+
+// acc[t] += (rows 64c .. 64c+63 of a packed [256][64] matrix)^T-product with a 64-feature chain vector: the K = 256
+// image has 32 feature groups per out tile, the chunk owns groups 8c .. 8c+7
+__device__ __forceinline__ void gemm_k256_chunk(f32x16 (&acc)[2], const f32x4* __restrict__ wp, int c, const f32x4 (&x)[8],
+                                                int lane) {
+    f32x4 a[8][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) a[u][t] = wp[(t * 32 + 8 * c + u) * 64 + lane];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        if (u + 2 < 8) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a[u + 2][t] = wp[(t * 32 + 8 * c + u + 2) * 64 + lane];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) mfma(acc[t], a[u][t][e], x[u][e]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Chain layout -> the lane's two heads: lane (h, j) gets heads 2h and 2h+1 of row j, 16 features each in natural
+// order (one exchange between the half-waves per register pair), times `scale`.
+__device__ __forceinline__ void x_to_heads(const f32x4 (&x)[8], float (&hd)[2][16], float scale) {
+    float qa[16], qb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        qa[r] = x[r >> 2][r & 3] * scale;
+        qb[r] = x[4 + (r >> 2)][r & 3] * scale;
+        half_swap(qa[r], qb[r]);
+    }
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+        const int src = 4 * (d >> 3) + (d & 3);
+        hd[0][d] = (d & 4) ? qb[src] : qa[src];
+        hd[1][d] = (d & 4) ? qb[8 + src] : qa[8 + src];
+    }
+}
+__device__ __forceinline__ void heads_to_x(const float (&hd)[2][16], f32x4 (&x)[8], float scale) {
+    float qa[16], qb[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+        const int dst = 4 * (d >> 3) + (d & 3);
+        if (d & 4) {
+            qb[dst] = hd[0][d] * scale;
+            qb[8 + dst] = hd[1][d] * scale;
+        } else {
+            qa[dst] = hd[0][d] * scale;
+            qa[8 + dst] = hd[1][d] * scale;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        half_swap(qa[r], qb[r]);
+        x[r >> 2][r & 3] = qa[r];
+        x[4 + (r >> 2)][r & 3] = qb[r];
+    }
+}
+
+// keras LayerNormalization(epsilon=1e-6): y (the summed input) becomes xhat; returns 1/sigma
+__device__ __forceinline__ float ln_normalise(f32x4 (&y)[8]) {
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (y[u][0] + y[u][1]) + (y[u][2] + y[u][3]);
+    const float mean = xhalf_sum(s) * (1.0f / 64.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = y[u][e] - mean;
+            y[u][e] = d;
+            q = fmaf(d, d, q);
+        }
+    const float inv = rsqrtf(xhalf_sum(q) * (1.0f / 64.0f) + 1e-6f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) y[u] *= inv;
+    return inv;
+}
+
+// out = xhat * gamma + beta with packed vectors (float4 index h*8 + u)
+__device__ __forceinline__ void ln_affine(const f32x4 (&xh)[8], const f32x4* __restrict__ g, const f32x4* __restrict__ b, int h,
+                                          f32x4 (&out)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) out[u] = xh[u] * g[h * 8 + u] + b[h * 8 + u];
+}
+
+// Backward of LayerNormalization for the lane's row: dy -> dsum = inv * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)).
+// The parameter gradients need column sums over rows: dy * xhat goes to the lane's row of imgA and dy to imgB (the
+// wavefront's own 32 rows of two idle images), from where colsum32 takes them.
+__device__ __forceinline__ void ln_backward(const f32x4 (&dy)[8], const f32x4 (&xh)[8], float inv, const f32x4* __restrict__ g,
+                                            int h, f32x4 (&dsum)[8], float* rowA, float* rowB) {
+    float s1 = 0.f, s2 = 0.f;
+    f32x4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        t[u] = dy[u] * xh[u];
+        dsum[u] = dy[u] * g[h * 8 + u];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s1 += dsum[u][e];
+            s2 = fmaf(dsum[u][e], xh[u][e], s2);
+        }
+    }
+    chain_store(rowA, h, t);
+    chain_store(rowB, h, dy);
+    s1 = xhalf_sum(s1) * (1.0f / 64.0f);
+    s2 = xhalf_sum(s2) * (1.0f / 64.0f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dsum[u] = inv * (dsum[u] - s1 - xh[u] * s2);
+}
+
+// ------------------------------------------------------------------------------------ forward
+
+template <int W>
+__global__ __launch_bounds__(512) void tb_fwd_kernel(TbFwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int NW = blockDim.x >> 6, rows_tile = NW * 32;
+    float* bufA = lds;
+    float* bufB = bufA + rows_tile * kLdsStride;
+    float* score = bufB + rows_tile * kLdsStride;   // [rows_tile] exp(tanh score)
+    float* alpha_s = score + rows_tile;             // [rows_tile] pooling weights
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const unsigned seed = p.step[kStepSeed];
+    const int S = p.S;
+    const int row = wave * 32 + j;
+    float* mine_a = bufA + row * kLdsStride;
+    float* mine_b = bufB + row * kLdsStride;
+    const int att_start = min(row / W, S - 1) * W;
+#pragma unroll 1
+    for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int64_t site0 = tile * S;
+        const int sites_here = (int)min((int64_t)S, p.n_sites - site0);
+        const int rows_valid = sites_here * W;
+        const bool row_ok = row < rows_valid;
+        const int64_t grow = site0 * W + row;
+        const int64_t ct = ((tile * NW + wave) * 8) * 64 + lane;
+        const int64_t cl = (tile * NW + wave) * 64 + lane;
+        f32x4 x1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            x1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row_ok) x1[u] = *reinterpret_cast<const f32x4*>(p.x1 + grow * 64 + 8 * u + 4 * h);
+        }
+#pragma unroll 1
+        for (int blk = 0; blk < 2; ++blk) {
+            const f32x4* T = p.P + kOffTb + blk * kTbSize;
+            const f32x4* tv = T + kTbVec;
+            const TbSave& sv = p.sv[blk];
+            __syncthreads();   // every wavefront is done with the previous contents of bufA / bufB
+            {
+                f32x16 acc[2];
+                f32x4 t[8];
+                acc_init_bias<2>(acc, tv + kVBk * kVec64, h, 8);
+                gemm_regs<8, 2>(acc, T + kTbWk, x1, lane);
+                acc_to_x<2>(acc, t);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sv.k[ct + u * 64] = t[u];
+                chain_store(mine_a, h, t);
+                acc_init_bias<2>(acc, tv + kVBv * kVec64, h, 8);
+                gemm_regs<8, 2>(acc, T + kTbWv, x1, lane);
+                acc_to_x<2>(acc, t);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sv.v[ct + u * 64] = t[u];
+                chain_store(mine_b, h, t);
+            }
+            float qh[2][16];
+            {
+                f32x16 acc[2];
+                f32x4 t[8];
+                acc_init_bias<2>(acc, tv + kVBq * kVec64, h, 8);
+                gemm_regs<8, 2>(acc, T + kTbWq, x1, lane);
+                acc_to_x<2>(acc, t);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sv.q[ct + u * 64] = t[u];
+                x_to_heads(t, qh, kQScale);
+            }
+            __syncthreads();   // K and V of the whole tile are in LDS
+            f32x4 o[8];
+            {
+                float oh[2][16];
+                f32x4 st;
+#pragma unroll
+                for (int hd = 0; hd < 2; ++hd) {
+                    float q1[1][16], o1[1][16], m1[1], r1[1];
+#pragma unroll
+                    for (int d = 0; d < 16; ++d) q1[0][d] = qh[hd][d];
+                    const int off = att_start * kLdsStride + 32 * h + 16 * hd;
+                    attend<W, 1>(bufA + off, bufB + off, q1, o1, m1, r1);
+#pragma unroll
+                    for (int d = 0; d < 16; ++d) oh[hd][d] = o1[0][d];
+                    st[2 * hd] = m1[0];
+                    st[2 * hd + 1] = r1[0];
+                }
+                sv.stat[cl] = st;
+                heads_to_x(oh, o, 1.0f);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sv.o[ct + u * 64] = o[u];
+            }
+            // output projection, dropout, residual, LayerNorm 1
+            f32x4 hres[8];
+            f32x2 iv;
+            {
+                f32x16 acc[2];
+                acc_init_bias<2>(acc, tv + kVBo * kVec64, h, 8);
+                gemm_regs<8, 2>(acc, T + kTbWo, o, lane);
+                f32x4 t[8];
+                acc_to_x<2>(acc, t);
+                dropout_chain(t, grow, h, seed, p.stream_base + 2 * blk, p.thr, p.scale);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] += x1[u];
+                iv[0] = ln_normalise(t);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sv.xh1[ct + u * 64] = t[u];
+                ln_affine(t, tv + kVLn1G * kVec64, tv + kVLn1B * kVec64, h, hres);
+            }
+            // FFN 64 -> 256 (swish) -> 64 in four hidden chunks, dropout, residual, LayerNorm 2
+            {
+                f32x16 acc_o[2];
+                acc_init_bias<2>(acc_o, tv + kVB2 * kVec64, h, 8);
+#pragma unroll 1
+                for (int c = 0; c < 4; ++c) {
+                    f32x16 acc_h[2];
+                    acc_init_bias<2>(acc_h, tv + 9 * kVec64 + 8 * c, h, 32);
+                    gemm_regs<8, 2, 2>(acc_h, T + kTbF1 + (2 * c) * 8 * 64, hres, lane);
+                    f32x4 hid[8];
+                    acc_to_x<2>(acc_h, hid);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hid[u][e] = swishf(hid[u][e]);
+                    gemm_k256_chunk(acc_o, T + kTbF2, c, hid, lane);
+                }
+                f32x4 t[8];
+                acc_to_x<2>(acc_o, t);
+                dropout_chain(t, grow, h, seed, p.stream_base + 2 * blk + 1, p.thr, p.scale);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] += hres[u];
+                iv[1] = ln_normalise(t);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sv.xh2[ct + u * 64] = t[u];
+                ln_affine(t, tv + kVLn2G * kVec64, tv + kVLn2B * kVec64, h, x1);
+            }
+            sv.inv[cl] = iv;
+        }
+        // ---- attention pooling (model.py:176-182): a = tanh(x.w + b), alpha = softmax over the site's positions
+        {
+            const f32x4* pv = p.P + kOffPoolV;
+            float part = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const f32x4 wv = pv[h * 8 + u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part = fmaf(x1[u][e], wv[e], part);
+            }
+            const float a = tanhf(xhalf_sum(part) + p.P[kOffPoolB][0]);
+            const float ew = __expf(a);     // |a| <= 1: no running maximum needed
+            __syncthreads();                // all attention reads of bufA are finished
+            chain_store(mine_a, h, x1);
+            if (h == 0) score[row] = ew;
+            __syncthreads();
+            float den = 0.f;
+#pragma unroll 3
+            for (int t = 0; t < W; ++t) den += score[att_start + t];
+            const float al = ew / den;
+            if (h == 0) alpha_s[row] = al;
+            p.pool[cl] = f32x2{a, al};
+            __syncthreads();
+            for (int oi = tid; oi < sites_here * 64; oi += blockDim.x) {
+                const int s = oi >> 6, f = oi & 63;
+                const float* ap = alpha_s + s * W;
+                const float* xp = bufA + (s * W) * kLdsStride + f;
+                float acc = 0.f;
+#pragma unroll 3
+                for (int t = 0; t < W; ++t) acc = fmaf(ap[t], xp[t * kLdsStride], acc);
+                p.out[(site0 + s) * p.ldo + p.col_off + f] = acc;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ backward
+
+// One 64 x 64 weight-gradient unit: part_u (+)= X^T Y over the rows of the tile, X and Y being LDS images.  The
+// caller has put a barrier between writing the images and this call; the call ends with one barrier, after which
+// the images (not xchg) may be overwritten.  xchg: 4096 floats of LDS that nothing else uses across the call.
+// part_u: this workgroup's 4096 floats for the unit, accumulator order [block][register][lane].
+__device__ __forceinline__ void dw_unit(const float* imgX, const float* imgY, int NW, float* xchg, float* __restrict__ part_u,
+                                        bool first, int lane, int wave) {
+    const int hh = lane >> 5, i = lane & 31;
+    if (NW >= 4) {
+        // wavefront w: block w & 3 over row half w >> 2 (NW = 4: one "half" of all 128 rows)
+        const int b = wave & 3, sp = wave >> 2;
+        const float* ap = imgX + (sp * 128 + hh) * kLdsStride + 32 * (b >> 1) + i;
+        const float* bp = imgY + (sp * 128 + hh) * kLdsStride + 32 * (b & 1) + i;
+        float* dst = part_u + b * 1024 + lane;
+        f32x16 acc;
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) acc[rg] = 0.f;
+        if (sp == 0 && !first) {
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) acc[rg] = dst[rg * 64];
+        }
+#pragma unroll 8
+        for (int q = 0; q < 64; ++q) mfma(acc, ap[2 * q * kLdsStride], bp[2 * q * kLdsStride]);
+        if (sp == 1) {
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) xchg[(b * 16 + rg) * 64 + lane] = acc[rg];
+        }
+        __syncthreads();
+        if (sp == 0) {
+            if (NW == 8) {
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) acc[rg] += xchg[(b * 16 + rg) * 64 + lane];
+            }
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) dst[rg * 64] = acc[rg];
+        }
+    } else {
+        // one or two wavefronts: 4 / NW blocks each over all rows
+        const int bpw = 4 / NW, steps = NW * 16;
+        for (int bi = 0; bi < bpw; ++bi) {
+            const int b = wave * bpw + bi;
+            const float* ap = imgX + hh * kLdsStride + 32 * (b >> 1) + i;
+            const float* bp = imgY + hh * kLdsStride + 32 * (b & 1) + i;
+            float* dst = part_u + b * 1024 + lane;
+            f32x16 acc;
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) acc[rg] = first ? 0.f : dst[rg * 64];
+#pragma unroll 8
+            for (int q = 0; q < steps; ++q) mfma(acc, ap[2 * q * kLdsStride], bp[2 * q * kLdsStride]);
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) dst[rg * 64] = acc[rg];
+        }
+        __syncthreads();
+    }
+}
+
+// attention backward, lane = query row, one head: dq = sum_t dz_t k_t with dz_t = p_t (dO.v_t - D),
+// p_t = exp2(q.k_t - m) * rden (q scaled by log2(e)/4 as in the forward pass)
+template <int W>
+__device__ __forceinline__ void attn_bwd_q(const float* kp, const float* vp, const float (&q)[16], const float (&dO)[16], float m,
+                                           float rden, float D, float (&dq)[16]) {
+    f32x4 q4[4], d4[4], acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        q4[i] = f32x4{q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]};
+        d4[i] = f32x4{dO[4 * i], dO[4 * i + 1], dO[4 * i + 2], dO[4 * i + 3]};
+        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 3
+    for (int t = 0; t < W; ++t) {
+        f32x4 k[4], v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            k[i] = *reinterpret_cast<const f32x4*>(kp + t * kLdsStride + 4 * i);
+            v[i] = *reinterpret_cast<const f32x4*>(vp + t * kLdsStride + 4 * i);
+        }
+        f32x4 s4 = q4[0] * k[0], p4 = d4[0] * v[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) {
+            s4 += q4[i] * k[i];
+            p4 += d4[i] * v[i];
+        }
+        const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        const float dp = (p4[0] + p4[1]) + (p4[2] + p4[3]);
+        const float pr = __builtin_amdgcn_exp2f(s - m) * rden;
+        const float dz = pr * (dp - D);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += dz * k[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dq[4 * i + e] = acc[i][e];
+}
+
+// attention backward, lane = key row, one head: dk = sum_i dz_i q_i, dv = sum_i p_i dO_i over the site's query rows;
+// qp / dop: scaled q and dO rows of the site in LDS, st: {max, 1/den, D} per (row, head) in three arrays `sstride` apart
+template <int W>
+__device__ __forceinline__ void attn_bwd_kv(const float* qp, const float* dop, const float* st, int sstride, const float (&k)[16],
+                                            const float (&v)[16], float (&dk)[16], float (&dv)[16]) {
+    f32x4 k4[4], v4[4], ak[4], av[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        k4[i] = f32x4{k[4 * i], k[4 * i + 1], k[4 * i + 2], k[4 * i + 3]};
+        v4[i] = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+        ak[i] = av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 3
+    for (int t = 0; t < W; ++t) {
+        f32x4 q[4], d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            q[i] = *reinterpret_cast<const f32x4*>(qp + t * kLdsStride + 4 * i);
+            d[i] = *reinterpret_cast<const f32x4*>(dop + t * kLdsStride + 4 * i);
+        }
+        const float m = st[t * 4], rden = st[sstride + t * 4], D = st[2 * sstride + t * 4];
+        f32x4 s4 = q[0] * k4[0], p4 = d[0] * v4[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) {
+            s4 += q[i] * k4[i];
+            p4 += d[i] * v4[i];
+        }
+        const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        const float dp = (p4[0] + p4[1]) + (p4[2] + p4[3]);
+        const float pr = __builtin_amdgcn_exp2f(s - m) * rden;
+        const float dz = pr * (dp - D);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ak[i] += dz * q[i];
+            av[i] += pr * d[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dk[4 * i + e] = ak[i][e];
+            dv[4 * i + e] = av[i][e];
+        }
+}
+
+constexpr int kXreg = 4096;                        // floats: exchange buffer of dw_unit / softmax statistics / pooling scores
+constexpr float kLn2 = 0.69314718055994530942f;
+
+// index of a block's vectors in the partial buffer
+enum TbVecSlot { kSG2 = 0, kSB2, kSFb2, kSFb1, kSG1 = kSFb1 + 4, kSB1, kSBo, kSBq, kSBk, kSBv, kSlotsPerBlock = 14 };
+constexpr int kSPoolW = 2 * kSlotsPerBlock, kSPoolB = kSPoolW + 1;
+static_assert(kSPoolB < kTbVecs, "vector slots");
+
+template <int W>
+__global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int NW = blockDim.x >> 6, rows_tile = NW * 32;
+    float* bufA = lds;
+    float* bufB = bufA + rows_tile * kLdsStride;
+    float* xreg = bufB + rows_tile * kLdsStride;
+    float* vacc = xreg + kXreg;                     // [kTbVecs][64] column sums of this workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const unsigned seed = p.step[kStepSeed];
+    const int S = p.S;
+    const int row = wave * 32 + j;
+    float* own_a = bufA + wave * 32 * kLdsStride;
+    float* own_b = bufB + wave * 32 * kLdsStride;
+    float* mine_a = own_a + j * kLdsStride;
+    float* mine_b = own_b + j * kLdsStride;
+    const int att_start = min(row / W, S - 1) * W;
+    float* part = p.part + (size_t)blockIdx.x * kTbPartStride;
+    for (int i = tid; i < kTbVecs * 64; i += blockDim.x) vacc[i] = 0.f;
+    __syncthreads();
+    bool first = true;
+#pragma unroll 1
+    for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int64_t site0 = tile * S;
+        const int sites_here = (int)min((int64_t)S, p.n_sites - site0);
+        const int rows_valid = sites_here * W;
+        const bool row_ok = row < rows_valid;
+        const int64_t grow = site0 * W + row;
+        const int64_t ct = ((tile * NW + wave) * 8) * 64 + lane;
+        const int64_t cl = (tile * NW + wave) * 64 + lane;
+        f32x4 dy[8];   // gradient w.r.t. the output of the block in hand
+        __syncthreads();   // the previous tile's last exchange through xreg has been read
+        // ---- attention pooling backward: dx_t = alpha_t dout + dz_t w, dz_t = alpha_t (dalpha_t - sum alpha dalpha)(1 - a_t^2)
+        {
+            const f32x4* tv1 = p.P + kOffTb + kTbSize + kTbVec;
+            const f32x4* pv = p.P + kOffPoolV;
+            f32x4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = p.sv[1].xh2[ct + u * 64];
+            ln_affine(x, tv1 + kVLn2G * kVec64, tv1 + kVLn2B * kVec64, h, x);
+            const f32x2 pa = p.pool[cl];
+            const float* dsite = p.dout + (site0 + row / W) * p.ldd + p.col_off;
+            f32x4 ds[8];
+            float dal = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                ds[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (row_ok) ds[u] = *reinterpret_cast<const f32x4*>(dsite + 8 * u + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dal = fmaf(ds[u][e], x[u][e], dal);
+            }
+            dal = xhalf_sum(dal);
+            if (h == 0) xreg[row] = row_ok ? pa[1] * dal : 0.f;
+            __syncthreads();
+            float dot = 0.f;
+#pragma unroll 3
+            for (int t = 0; t < W; ++t) dot += xreg[att_start + t];
+            const float dz = row_ok ? pa[1] * (dal - dot) * (1.0f - pa[0] * pa[0]) : 0.f;
+            const float al = row_ok ? pa[1] : 0.f;
+            f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                dy[u] = al * ds[u] + dz * pv[h * 8 + u];
+                t[u] = dz * x[u];
+            }
+            chain_store(mine_a, h, t);
+            wave_fence();
+            atomicAdd(&vacc[kSPoolW * 64 + lane], colsum32(own_a, lane));
+            float dzs = h == 0 ? dz : 0.f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) dzs += __shfl_xor(dzs, o);
+            if (lane == 0) atomicAdd(&vacc[kSPoolB * 64], dzs);
+            wave_fence();
+            __syncthreads();   // the scores in xreg have been read
+        }
+#pragma unroll 1
+        for (int blk = 1; blk >= 0; --blk) {
+            const f32x4* T = p.P + kOffTb + blk * kTbSize;
+            const f32x4* tv = T + kTbVec;
+            const f32x4* TT = p.PT + blk * kBtSize;
+            const TbSave& sv = p.sv[blk];
+            float* pu = part + (size_t)blk * 12 * 4096;
+            float* va = vacc + blk * kSlotsPerBlock * 64 + lane;
+            const f32x2 iv = sv.inv[cl];
+            // ---- LayerNorm 2 backward: dy -> dsum = d(h + f2)
+            f32x4 dsum[8];
+            {
+                f32x4 xh[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xh[u] = sv.xh2[ct + u * 64];
+                ln_backward(dy, xh, iv[1], tv + kVLn2G * kVec64, h, dsum, mine_a, mine_b);
+                wave_fence();
+                atomicAdd(va + kSG2 * 64, colsum32(own_a, lane));
+                atomicAdd(va + kSB2 * 64, colsum32(own_b, lane));
+                wave_fence();
+            }
+            f32x4 df2[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) df2[u] = dsum[u];
+            dropout_chain(df2, grow, h, seed, p.stream_base + 2 * blk + 1, p.thr, p.scale);
+            f32x4 hx[8];
+            {
+                f32x4 xh[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xh[u] = sv.xh1[ct + u * 64];
+                ln_affine(xh, tv + kVLn1G * kVec64, tv + kVLn1B * kVec64, h, hx);
+            }
+            // ---- feed-forward layers backward; the hidden layer is rebuilt in four 64-wide chunks
+            f32x16 acc_dh[2];
+            x_to_acc(dsum, acc_dh);
+#pragma unroll 1
+            for (int c = 0; c < 4; ++c) {
+                f32x4 g[8];
+                {
+                    f32x16 acc_f[2];
+                    acc_init_bias<2>(acc_f, tv + 9 * kVec64 + 8 * c, h, 32);
+                    gemm_regs<8, 2, 2>(acc_f, T + kTbF1 + (2 * c) * 8 * 64, hx, lane);     // f1_c = h W1[:, chunk] + b1
+                    f32x4 u_[8];
+                    acc_to_x<2>(acc_f, u_);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float a = u_[u][e];
+                            const float sg = fast_rcp(1.0f + __expf(-a));
+                            u_[u][e] = a * sg;                                   // swish(f1_c)
+                            g[u][e] = sg * (1.0f + a * (1.0f - sg));             // swish'(f1_c)
+                        }
+                    chain_store(mine_a, h, u_);
+                }
+                chain_store(mine_b, h, df2);
+                if (c == 0) {
+                    wave_fence();
+                    atomicAdd(va + kSFb2 * 64, colsum32(own_b, lane));
+                }
+                __syncthreads();
+                dw_unit(bufA, bufB, NW, xreg, pu + (4 + c) * 4096, first, lane, wave);     // dW2[chunk, :] += u_c^T d(f2)
+                f32x4 d1[8];
+                {
+                    f32x16 acc_u[2];
+                    acc_zero<2>(acc_u);
+                    gemm_regs<8, 2, 2>(acc_u, TT + kBtW2T + (2 * c) * 8 * 64, df2, lane);   // d(u_c) = d(f2) W2[chunk, :]^T
+                    acc_to_x<2>(acc_u, d1);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) d1[u] *= g[u];                             // d(f1_c)
+                }
+                chain_store(mine_a, h, hx);
+                chain_store(mine_b, h, d1);
+                wave_fence();
+                atomicAdd(va + (kSFb1 + c) * 64, colsum32(own_b, lane));
+                __syncthreads();
+                dw_unit(bufA, bufB, NW, xreg, pu + c * 4096, first, lane, wave);           // dW1[:, chunk] += h^T d(f1_c)
+                gemm_k256_chunk(acc_dh, TT + kBtW1T, c, d1, lane);                         // d(h) += d(f1_c) W1[:, chunk]^T
+            }
+            // ---- LayerNorm 1 backward: d(h) -> dsum = d(x + ao)
+            {
+                f32x4 dh[8], xh[8];
+                acc_to_x<2>(acc_dh, dh);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) xh[u] = sv.xh1[ct + u * 64];
+                ln_backward(dh, xh, iv[0], tv + kVLn1G * kVec64, h, dsum, mine_a, mine_b);
+                wave_fence();
+                atomicAdd(va + kSG1 * 64, colsum32(own_a, lane));
+                atomicAdd(va + kSB1 * 64, colsum32(own_b, lane));
+                wave_fence();
+            }
+            // ---- output projection backward
+            f32x4 o[8], dO[8];
+            {
+                f32x4 dao[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    dao[u] = dsum[u];
+                    o[u] = sv.o[ct + u * 64];
+                }
+                dropout_chain(dao, grow, h, seed, p.stream_base + 2 * blk, p.thr, p.scale);
+                chain_store(mine_a, h, o);
+                chain_store(mine_b, h, dao);
+                wave_fence();
+                atomicAdd(va + kSBo * 64, colsum32(own_b, lane));
+                __syncthreads();
+                dw_unit(bufA, bufB, NW, xreg, pu + 8 * 4096, first, lane, wave);           // dWo += o^T d(ao)
+                f32x16 acc[2];
+                acc_zero<2>(acc);
+                gemm_regs<8, 2>(acc, TT + kBtWoT, dao, lane);                              // d(o) = d(ao) Wo^T
+                acc_to_x<2>(acc, dO);
+            }
+            // ---- attention backward
+            f32x4 dq[8], dk[8], dv[8];
+            {
+                f32x4 qx[8], kx[8], vx[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    qx[u] = sv.q[ct + u * 64];
+                    kx[u] = sv.k[ct + u * 64];
+                    vx[u] = sv.v[ct + u * 64];
+                }
+                chain_store(mine_a, h, kx);
+                chain_store(mine_b, h, vx);
+                float qs[2][16], doh[2][16], D[2];
+                x_to_heads(qx, qs, kQScale);
+                x_to_heads(dO, doh, 1.0f);
+                {
+                    float oh[2][16];
+                    x_to_heads(o, oh, 1.0f);
+#pragma unroll
+                    for (int hd = 0; hd < 2; ++hd) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int d = 0; d < 16; ++d) s = fmaf(doh[hd][d], oh[hd][d], s);
+                        D[hd] = s;
+                    }
+                }
+                const f32x4 st = sv.stat[cl];
+                __syncthreads();   // K and V of the tile are in LDS
+                float gh[2][16];
+#pragma unroll
+                for (int hd = 0; hd < 2; ++hd) {
+                    const int off = att_start * kLdsStride + 32 * h + 16 * hd;
+                    attn_bwd_q<W>(bufA + off, bufB + off, qs[hd], doh[hd], st[2 * hd], st[2 * hd + 1], D[hd], gh[hd]);
+                }
+                heads_to_x(gh, dq, 0.25f);
+                __syncthreads();   // K and V have been read
+                {
+                    f32x4 t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] = qx[u] * kQScale;
+                    chain_store(mine_a, h, t);
+                    chain_store(mine_b, h, dO);
+#pragma unroll
+                    for (int hd = 0; hd < 2; ++hd) {
+                        xreg[row * 4 + 2 * h + hd] = st[2 * hd];
+                        xreg[rows_tile * 4 + row * 4 + 2 * h + hd] = st[2 * hd + 1];
+                        xreg[2 * rows_tile * 4 + row * 4 + 2 * h + hd] = D[hd];
+                    }
+                }
+                __syncthreads();   // scaled Q, dO and the statistics of the tile are in LDS
+                float kh[2][16], vh[2][16], gk[2][16], gv[2][16];
+                x_to_heads(kx, kh, 1.0f);
+                x_to_heads(vx, vh, 1.0f);
+#pragma unroll
+                for (int hd = 0; hd < 2; ++hd) {
+                    const int off = att_start * kLdsStride + 32 * h + 16 * hd;
+                    attn_bwd_kv<W>(bufA + off, bufB + off, xreg + att_start * 4 + 2 * h + hd, rows_tile * 4, kh[hd], vh[hd], gk[hd],
+                                   gv[hd]);
+                }
+                heads_to_x(gk, dk, kLn2);
+                heads_to_x(gv, dv, 1.0f);
+                if (!row_ok) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) dq[u] = dk[u] = dv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                __syncthreads();   // Q and dO have been read
+            }
+            // ---- Q / K / V projections backward: weight gradients from the block input, then d(x)
+            {
+                f32x4 xin[8];
+                if (blk == 0) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        xin[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (row_ok) xin[u] = *reinterpret_cast<const f32x4*>(p.x1 + grow * 64 + 8 * u + 4 * h);
+                    }
+                } else {
+                    const f32x4* tv0 = p.P + kOffTb + kTbVec;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) xin[u] = p.sv[0].xh2[ct + u * 64];
+                    ln_affine(xin, tv0 + kVLn2G * kVec64, tv0 + kVLn2B * kVec64, h, xin);
+                }
+                chain_store(mine_a, h, xin);
+            }
+            chain_store(mine_b, h, dq);
+            wave_fence();
+            atomicAdd(va + kSBq * 64, colsum32(own_b, lane));
+            __syncthreads();
+            dw_unit(bufA, bufB, NW, xreg, pu + 9 * 4096, first, lane, wave);
+            chain_store(mine_b, h, dk);
+            wave_fence();
+            atomicAdd(va + kSBk * 64, colsum32(own_b, lane));
+            __syncthreads();
+            dw_unit(bufA, bufB, NW, xreg, pu + 10 * 4096, first, lane, wave);
+            chain_store(mine_b, h, dv);
+            wave_fence();
+            atomicAdd(va + kSBv * 64, colsum32(own_b, lane));
+            __syncthreads();
+            dw_unit(bufA, bufB, NW, xreg, pu + 11 * 4096, first, lane, wave);
+            {
+                f32x16 acc[2];
+                x_to_acc(dsum, acc);
+                gemm_regs<8, 2>(acc, TT + kBtWqT, dq, lane);
+                gemm_regs<8, 2>(acc, TT + kBtWkT, dk, lane);
+                gemm_regs<8, 2>(acc, TT + kBtWvT, dv, lane);
+                acc_to_x<2>(acc, dy);
+            }
+        }
+        if (row_ok) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x4*>(p.dx1 + grow * 64 + 8 * u + 4 * h) = dy[u];
+        }
+        first = false;
+    }
+    __syncthreads();
+    for (int i = tid; i < kTbVecs * 64; i += blockDim.x) part[kTbUnits * 4096 + i] = vacc[i];
+}
+
+// ------------------------------------------------------------------------------------ partial sums -> gradients
+
+struct UnitTab {
+    float* dst[kTbUnits];     // element (k, n) of unit u lives at dst[u][k*ld[u] + n]
+    int ld[kTbUnits];
+};
+struct VecTab {
+    float* dst[kTbVecs];
+    int len[kTbVecs];
+};
+
+// grid (16, units): thread o of a unit is accumulator element [block o>>10][register (o>>6)&15][lane o&63]
+__global__ __launch_bounds__(256) void reduce_units_kernel(const float* __restrict__ part, int nparts, UnitTab tab) {
+    const int u = blockIdx.y;
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    const float* src = part + (size_t)u * 4096 + o;
+    float a0 = 0.f, a1 = 0.f;
+    int pi = 0;
+    for (; pi + 1 < nparts; pi += 2) {
+        a0 += src[(size_t)pi * kTbPartStride];
+        a1 += src[(size_t)(pi + 1) * kTbPartStride];
+    }
+    if (pi < nparts) a0 += src[(size_t)pi * kTbPartStride];
+    const int b = o >> 10, rg = (o >> 6) & 15, lane = o & 63;
+    const int k = 32 * (b >> 1) + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5), n = 32 * (b & 1) + (lane & 31);
+    tab.dst[u][(size_t)k * tab.ld[u] + n] += a0 + a1;
+}
+
+// grid (vectors): 64 threads
+__global__ __launch_bounds__(64) void reduce_vecs_kernel(const float* __restrict__ part, int nparts, VecTab tab) {
+    const int v = blockIdx.x, f = threadIdx.x;
+    if (f >= tab.len[v]) return;
+    const float* src = part + (size_t)kTbUnits * 4096 + v * 64 + f;
+    float a = 0.f;
+    for (int pi = 0; pi < nparts; ++pi) a += src[(size_t)pi * kTbPartStride];
+    tab.dst[v][f] += a;
+}
+
+// ------------------------------------------------------------------------------------ launchers
+
+static size_t fwd_lds(int NW) { return ((size_t)2 * NW * 32 * kLdsStride + 2 * NW * 32) * sizeof(float); }
+static size_t bwd_lds(int NW) { return ((size_t)2 * NW * 32 * kLdsStride + kXreg + kTbVecs * 64) * sizeof(float); }
+
+template <typename K>
+static hipError_t lds_opt_in(K kernel, bool (&done)[64], size_t bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (done[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) done[dev] = true;
+    return e;
+}
+
+static bool tile_ok(int wlen, int S, int NW, int64_t n, int64_t ntiles) {
+    return (wlen == 21 || wlen == 33 || wlen == 51) && (NW == 1 || NW == 2 || NW == 4 || NW == 8) && S >= 1 && S * wlen <= NW * 32 &&
+           ntiles == (n + S - 1) / S;
+}
+
+template <int W>
+static hipError_t launch_fwd(const TbFwdArgs& a, int NW, hipStream_t st) {
+    static bool done[64] = {};
+    hipError_t e = lds_opt_in(&tb_fwd_kernel<W>, done, fwd_lds(8));
+    if (e != hipSuccess) return e;
+    const int64_t grid = a.ntiles < 1024 ? a.ntiles : 1024;
+    hipLaunchKernelGGL(tb_fwd_kernel<W>, dim3((unsigned)grid), dim3(64 * NW), fwd_lds(NW), st, a);
+    return hipGetLastError();
+}
+
+hipError_t t_tb_fwd(const TbFwdArgs& a, int wlen, int NW, hipStream_t st) {
+    if (a.n_sites == 0) return hipSuccess;
+    if (!tile_ok(wlen, a.S, NW, a.n_sites, a.ntiles)) return hipErrorInvalidValue;
+    switch (wlen) {
+        case 21: return launch_fwd<21>(a, NW, st);
+        case 33: return launch_fwd<33>(a, NW, st);
+        default: return launch_fwd<51>(a, NW, st);
+    }
+}
+
+template <int W>
+static hipError_t launch_bwd(const TbBwdArgs& a, int NW, int grid, hipStream_t st) {
+    static bool done[64] = {};
+    hipError_t e = lds_opt_in(&tb_bwd_kernel<W>, done, bwd_lds(8));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tb_bwd_kernel<W>, dim3((unsigned)grid), dim3(64 * NW), bwd_lds(NW), st, a);
+    return hipGetLastError();
+}
+
+hipError_t t_tb_bwd(const TbBwdArgs& a, const TbGrads& g, int wlen, int NW, hipStream_t st) {
+    if (a.n_sites == 0) return hipSuccess;
+    if (!tile_ok(wlen, a.S, NW, a.n_sites, a.ntiles)) return hipErrorInvalidValue;
+    const int grid = (int)(a.ntiles < kTbMaxParts ? a.ntiles : kTbMaxParts);
+    hipError_t e;
+    switch (wlen) {
+        case 21: e = launch_bwd<21>(a, NW, grid, st); break;
+        case 33: e = launch_bwd<33>(a, NW, grid, st); break;
+        default: e = launch_bwd<51>(a, NW, grid, st); break;
+    }
+    if (e != hipSuccess) return e;
+    UnitTab ut;
+    VecTab vt;
+    for (int b = 0; b < 2; ++b) {
+        for (int c = 0; c < 4; ++c) {
+            ut.dst[b * 12 + c] = g.w1[b] + 64 * c;              // dW1[:, 64c ..]  (raw [64][256])
+            ut.ld[b * 12 + c] = 256;
+            ut.dst[b * 12 + 4 + c] = g.w2[b] + 64 * c * 64;     // dW2[64c .., :]  (raw [256][64])
+            ut.ld[b * 12 + 4 + c] = 64;
+        }
+        float* sq[4] = {g.wo[b], g.wq[b], g.wk[b], g.wv[b]};
+        for (int i = 0; i < 4; ++i) {
+            ut.dst[b * 12 + 8 + i] = sq[i];
+            ut.ld[b * 12 + 8 + i] = 64;
+        }
+        float** vd = vt.dst + b * kSlotsPerBlock;
+        int* vl = vt.len + b * kSlotsPerBlock;
+        for (int i = 0; i < kSlotsPerBlock; ++i) vl[i] = 64;
+        vd[kSG2] = g.ln2g[b]; vd[kSB2] = g.ln2b[b]; vd[kSFb2] = g.b2[b];
+        for (int c = 0; c < 4; ++c) vd[kSFb1 + c] = g.b1[b] + 64 * c;
+        vd[kSG1] = g.ln1g[b]; vd[kSB1] = g.ln1b[b]; vd[kSBo] = g.bo[b];
+        vd[kSBq] = g.bq[b]; vd[kSBk] = g.bk[b]; vd[kSBv] = g.bv[b];
+        vd[13] = g.bv[b];
+        vl[13] = 0;
+    }
+    vt.dst[kSPoolW] = g.poolw; vt.len[kSPoolW] = 64;
+    vt.dst[kSPoolB] = g.poolb; vt.len[kSPoolB] = 1;
+    hipLaunchKernelGGL(reduce_units_kernel, dim3(16, kTbUnits), dim3(256), 0, st, a.part, grid, ut);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(reduce_vecs_kernel, dim3(kTbVecs), dim3(64), 0, st, a.part, grid, vt);
+    return hipGetLastError();
+}
+
+}  // namespace dptm

@@ -102,58 +102,96 @@ hipError_t t_adamw(float* w, const float* g, float* m, float* v, const uint8_t* 
                    float lr_t, float wd, float b1, float b2, float eps, float gscale, hipStream_t st);
 
 
-// ---- fused row-wise kernels (dptm_train_fused.hip)
+// ---- fused sequence-branch kernels (dptm_train_branch.hip)
 typedef float f32x4_tr __attribute__((ext_vector_type(4)));
+typedef float f32x2_tr __attribute__((ext_vector_type(2)));
 
-// one weight image in MFMA fragment order (dptm_layout.h) of the logical matrix M [K][N]:
-// M = src (raw [K][N]) or, with transpose, M[k][n] = src[n][k] (raw [N][K])
+// One entry of the per-step weight-image build (MFMA fragment order, see dptm_layout.h):
+//   kind 0  packed matrix of the logical M [K][N]: M = src (raw [K][N]) or, with transpose, M[k][n] = src[n][k]
+//   kind 1  packed feature vector of K features
+//   kind 2  plain copy of K floats
 struct PackJob {
     const float* src;
     float* dst;
-    int K, N, transpose;
+    int kind, K, N, transpose;
 };
 hipError_t t_pack(const PackJob* jobs_dev, int n_jobs, hipStream_t st);
 
-// out = LayerNorm(h + dropout(W2 swish(W1 h + b1) + b2)) for R rows of 64 features
-struct FfnFwdArgs {
-    const float* h;            // [R][64] row-major
-    const f32x4_tr* w1p;       // image of W1 (K 64, N 256)
-    const f32x4_tr* w2p;       // image of W2 (K 256, N 64)
-    const float *b1, *b2, *gamma, *beta;
-    float* out;                // [R][64] row-major
-    f32x4_tr* xhat;            // [ceil(R/32)][8][64] float4: normalised rows, 32-row tiles in chain layout
-    float* inv;                // [R] 1/sigma of the LayerNorm
-    int64_t R;
-    const unsigned* step;      // per-step scalars (dropout seed)
-    unsigned stream, thr;      // dropout stream id and keep threshold (0: no dropout)
-    float scale;               // 1 / (1 - rate)
-};
-hipError_t t_ffn_fwd(const FfnFwdArgs& a, hipStream_t st);
+// transposed weight images of one TransformerBlock for the backward kernel, offsets in float4 units
+constexpr int kBtWqT = 0;                    // Wq^T, Wk^T, Wv^T, Wo^T: packed 64 x 64
+constexpr int kBtWkT = kBtWqT + 1024;
+constexpr int kBtWvT = kBtWkT + 1024;
+constexpr int kBtWoT = kBtWvT + 1024;
+constexpr int kBtW2T = kBtWoT + 1024;        // W2^T as a [64][256] matrix
+constexpr int kBtW1T = kBtW2T + 4096;        // W1^T as a [256][64] matrix
+constexpr int kBtSize = kBtW1T + 4096;
 
-constexpr int kFfnPartStride = 33280;   // floats per workgroup of partial gradients (33,216 used)
-struct FfnBwdArgs {
-    const float* dout;         // [R][64] gradient w.r.t. the block output
-    const f32x4_tr* xhat;      // as written by the forward kernel
-    const float* inv;
-    const float* h;            // [R][64] the forward input
-    const f32x4_tr* w1p;       // image of W1 (K 64, N 256)
-    const f32x4_tr* w2tp;      // image of W2^T (K 64, N 256)
-    const f32x4_tr* w1tp;      // image of W1^T (K 256, N 64)
-    const float *b1, *gamma;
-    float* dh;                 // [R][64] gradient w.r.t. h
-    float* part;               // [t_ffn_bwd_max_parts()][kFfnPartStride] scratch for partial gradients
-    int64_t R;
+// A tile of the fused kernels = S whole sites (S * wlen rows) handled by NW wavefronts of 32 rows each.
+struct TileCfg {
+    int S, NW;
+    int64_t ntiles;
+};
+TileCfg t_tile_cfg(int64_t n_sites, int wlen);
+// rows (incl. padding) that the chain-tiled activation arrays need for any batch up to max_sites
+int64_t t_tile_rows_max(int64_t max_sites, int wlen);
+
+// Saved activations of one TransformerBlock in "chain-tiled" order: float4 index ((tile*NW + wave)*8 + u)*64 + lane
+// holds features 8u + 4(lane>>5) .. +3 of row wave*32 + (lane&31) of the tile; per-lane arrays use
+// (tile*NW + wave)*64 + lane.
+struct TbSave {
+    f32x4_tr *q, *k, *v, *o, *xh1, *xh2;
+    f32x4_tr* stat;        // softmax statistics of heads 2(lane>>5), 2(lane>>5)+1 of the lane's row: {max, 1/den} x 2
+    f32x2_tr* inv;         // 1/sigma of the two LayerNormalizations
+};
+
+struct TbFwdArgs {
+    const f32x4_tr* P;     // packed branch image (dptm_layout.h), built from this step's weights
+    const float* x1;       // [sites*wlen][64] input of the first block (row-major)
+    TbSave sv[2];
+    f32x2_tr* pool;        // per lane: {tanh score, pooling weight alpha}
+    float* out;            // pooled rows: out[site*ldo + col_off + f]
+    int64_t ldo;
+    int col_off;
+    int64_t n_sites;
+    int S;
+    int64_t ntiles;
+    const unsigned* step;  // per-step scalars (dropout seed)
+    unsigned stream_base;  // dropout streams: +2*blk attention output, +2*blk+1 feed-forward output
+    unsigned thr;          // keep threshold (0: no dropout)
+    float scale;           // 1 / (1 - rate)
+};
+hipError_t t_tb_fwd(const TbFwdArgs& a, int wlen, int NW, hipStream_t st);
+
+// partial parameter gradients of one workgroup of the backward kernel (floats):
+//   24 weight-gradient units of 4096 (MFMA accumulator order) | 30 vectors of 64
+constexpr int kTbUnits = 24;
+constexpr int kTbVecs = 30;
+constexpr int kTbPartStride = kTbUnits * 4096 + kTbVecs * 64 + 128;   // rounded to a multiple of 256
+constexpr int kTbMaxParts = 256;
+struct TbBwdArgs {
+    const f32x4_tr* P;
+    const f32x4_tr* PT;    // [2][kBtSize] transposed images
+    const float* x1;
+    TbSave sv[2];
+    const f32x2_tr* pool;
+    const float* dout;     // gradient of the pooled rows: dout[site*ldd + col_off + f]
+    int64_t ldd;
+    int col_off;
+    float* dx1;            // [sites*wlen][64] gradient w.r.t. x1 (row-major)
+    float* part;           // [grid][kTbPartStride]
+    int64_t n_sites;
+    int S;
+    int64_t ntiles;
     const unsigned* step;
-    unsigned stream, thr;
+    unsigned stream_base, thr;
     float scale;
 };
-struct FfnGrads { float *dw1, *db1, *dw2, *db2, *dgamma, *dbeta; };   // gradient tensors (raw layouts), added to
-struct PartSegs {
-    int n, total;
-    int src[8];
-    float* dst[7];
+// gradient tensors (raw layouts) that the partial sums are added to
+struct TbGrads {
+    float *wq[2], *bq[2], *wk[2], *bk[2], *wv[2], *bv[2], *wo[2], *bo[2];
+    float *w1[2], *b1[2], *w2[2], *b2[2], *ln1g[2], *ln1b[2], *ln2g[2], *ln2b[2];
+    float *poolw, *poolb;
 };
-hipError_t t_ffn_bwd(const FfnBwdArgs& a, const FfnGrads& g, hipStream_t st);
-int t_ffn_bwd_max_parts();
+hipError_t t_tb_bwd(const TbBwdArgs& a, const TbGrads& g, int wlen, int NW, hipStream_t st);
 
 }  // namespace dptm
