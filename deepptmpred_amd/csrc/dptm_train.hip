@@ -104,7 +104,7 @@ struct Arena {
 
 struct BranchAct {
     int wlen;
-    float *x0, *s, *a1, *y1, *z1, *a2, *y2, *x1, *mi1, *mi2;   // mi = mean|inv of a BatchNorm
+    ConvSave cs;                       // convolution block: shortcut output and the two pre-activations
     TbSave sv[2];                      // what the fused TransformerBlock kernels keep for the backward pass
     f32x2_tr* pool;                    // per row: tanh score and pooling weight
 };
@@ -132,7 +132,8 @@ struct dptm_trainer {
     // Scratch of one concurrent lane of the step: the three sequence branches run on side streams next to
     // the per-site layers, so each owns its gradient scratch ([rows][64] / [rows][256]) and BatchNorm sums.
     struct Scratch {
-        float *g64a = nullptr, *g64b = nullptr, *g64c = nullptr, *g64d = nullptr, *bnsums_all = nullptr;
+        f32x4_tr *dx1 = nullptr, *dz1 = nullptr;   // chain-tiled gradients handed from one backward kernel to the next
+        float* bnsums_all = nullptr;
         float* part = nullptr;            // partial parameter gradients of the fused backward kernel, one slab per workgroup
     };
     Scratch sc[4];                        // [0..2] sequence branches, [3] per-site layers (BatchNorm sums only)
@@ -178,12 +179,10 @@ int alloc_acts(dptm_trainer* t) {
     for (int b = 0; b < 3; ++b) {
         BranchAct& a = t->ba[b];
         a.wlen = kW[b];
-        const size_t R = (size_t)B * kW[b], R64 = R * 64;
-        ok &= need(a.x0, R64) && need(a.s, R64) && need(a.a1, R64) && need(a.y1, R64) && need(a.z1, R64) &&
-              need(a.a2, R64) && need(a.y2, R64) && need(a.x1, R64) && need(a.mi1, 128) && need(a.mi2, 128);
         // chain-tiled arrays cover the padded rows of the largest tiling a batch up to max_batch can take
         const size_t RP = (size_t)t_tile_rows_max(B, kW[b]);
         auto need4 = [&](f32x4_tr*& p4, size_t rows) -> bool { float* f = nullptr; const bool k = need(f, rows * 64); p4 = reinterpret_cast<f32x4_tr*>(f); return k; };
+        ok &= need4(a.cs.s, RP) && need4(a.cs.a1, RP) && need4(a.cs.a2, RP);
         for (int i = 0; i < 2; ++i) {
             TbSave& q = a.sv[i];
             float *st = nullptr, *iv = nullptr;
@@ -207,9 +206,11 @@ int alloc_acts(dptm_trainer* t) {
         dptm_trainer::Scratch& s = t->sc[b];
         ok &= need(s.bnsums_all, 1024);
         if (b == 3) break;
-        const size_t RM = (size_t)B * kW[b];
-        ok &= need(s.g64a, RM * 64) && need(s.g64b, RM * 64) && need(s.g64c, RM * 64) && need(s.g64d, RM * 64) &&
-              need(s.part, (size_t)kTbMaxParts * kTbPartStride);
+        const size_t RP = (size_t)t_tile_rows_max(B, kW[b]);
+        float *d1 = nullptr, *d2 = nullptr;
+        ok &= need(d1, RP * 64) && need(d2, RP * 64) && need(s.part, (size_t)kTbMaxParts * kTbPartStride);
+        s.dx1 = reinterpret_cast<f32x4_tr*>(d1);
+        s.dz1 = reinterpret_cast<f32x4_tr*>(d2);
     }
     ok &= need(t->dconcat, B * 576) && need(t->d512a, B * 512) && need(t->d512b, B * 512) && need(t->d256a, B * 256) &&
           need(t->d256b, B * 256) && need(t->d128, B * 128);
@@ -219,10 +220,10 @@ int alloc_acts(dptm_trainer* t) {
 size_t arena_bytes(int64_t B) {
     size_t f = 0;
     for (int b = 0; b < 3; ++b) {
-        const size_t R = (size_t)B * kW[b], RP = (size_t)t_tile_rows_max(B, kW[b]);
-        f += R * 64 * 8 + 2 * 128;                                  // conv block activations
+        const size_t RP = (size_t)t_tile_rows_max(B, kW[b]);
+        f += RP * 64 * 3;                                           // conv block activations
         f += 2 * (RP * 64 * 6 + RP * 8 + RP * 4) + RP * 4;          // saved TransformerBlock activations, pooling
-        f += R * 64 * 4 + (size_t)kTbMaxParts * kTbPartStride;      // gradient scratch, partial gradients
+        f += RP * 64 * 2 + (size_t)kTbMaxParts * kTbPartStride;     // gradient hand-over, partial gradients
     }
     f += (size_t)B * (128 * 2 + 512 * 3 + 256 + 576 + 512 * 3 + 256 * 3 + 2);
     f += (4 + 2 * 10) * 1024 + 64 + (size_t)B * (576 + 1024 + 512 + 128);
@@ -299,55 +300,73 @@ GemmTnArgs gt(const float* x, int64_t ldx, int xoff, const float* dy, int64_t ld
     return a;
 }
 
-// conv1d 'same': out = sum_t shift_{t-1}(x) * K[t] + b, all taps in one product (K is [taps][64][64])
-int conv_fwd(const Ctx& c, const float* x, int kid, int bid, int taps, float* out, int64_t R, int wlen, float* swish_out = nullptr) {
-    GemmArgs a = ga(x, 64, c.w(kid), 64, c.w(bid), out, 64, 0, R, 64, 64, 0, wlen, 0);
-    a.taps = taps; a.tap_stride = 64 * 64; a.tap_dir = 1;
-    a.act_out = swish_out; a.lda = 64;
-    T_TRY(t_gemm(a, false, c.st));
-    return DPTM_OK;
-}
-// gradients of a conv: dK[t] += shift(x)^T dout, db += colsum(dout), dx (+)= sum_t shift_{-(t-1)}(dout) K[t]^T
-int conv_bwd(const Ctx& c, const float* x, const float* dout, int kid, int bid, int taps, float* dx, bool dx_acc, int64_t R, int wlen) {
-    {
-        GemmTnArgs g = gt(x, 64, 0, dout, 64, 0, c.g(kid), 64, c.g(bid), R, 64, 64, 0, wlen);
-        if (taps > 1) {      // the taps are independent products over shifted rows: one batched launch
-            g.batch = taps; g.bdw = 64 * 64; g.bshift_dir = 1;
-        }
-        T_TRY(t_gemm_tn(g, c.st));
-    }
-    if (dx) {
-        GemmArgs a = ga(dout, 64, c.w(kid), 64, nullptr, dx, 64, 0, R, 64, 64, 0, wlen, dx_acc ? 1 : 0);
-        a.taps = taps; a.tap_stride = 64 * 64; a.tap_dir = -1;
-        T_TRY(t_gemm(a, true, c.st));
-    }
-    return DPTM_OK;
-}
-
 struct Rates { float embed, conv, tb, dense; };
 
-int branch_fwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigned* seed, const Rates& rt) {
+// per-branch arguments shared by the four convolution-block kernels
+ConvArgs conv_args(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigned* seed, const Rates& rt, const TileCfg& tc) {
     dptm_trainer* t = c.t;
     BranchAct& a = t->ba[b];
     const BranchP& p = t->pm.br[b];
+    const float inv_rows = 1.0f / (float)global_rows(t, B * a.wlen);
+    ConvArgs f;
+    f.P = reinterpret_cast<const f32x4_tr*>(t->P + t->img_fwd[b]);
+    f.PT = reinterpret_cast<const f32x4_tr*>(t->P + t->img_bwd[b]);
+    f.tok = tok;
+    f.cs = a.cs;
+    f.stats1 = t->bn_slots + (size_t)p.bn1.slot * 1024;
+    f.stats2 = t->bn_slots + (size_t)p.bn2.slot * 1024;
+    // the batch statistics ride in the (otherwise unused) moving-stat slots of the gradient buffer
+    f.bn1 = BnFwd{f.stats1, inv_rows, c.w(p.bn1.gamma), c.w(p.bn1.beta), c.g(p.bn1.mean), c.g(p.bn1.var)};
+    float* own1 = t->bn_slots + (size_t)(kBnLayers + p.bn1.slot) * 1024;
+    float* own2 = t->bn_slots + (size_t)(kBnLayers + p.bn2.slot) * 1024;
+    // with synchronised BatchNorm the sums of the whole batch live in a second buffer (filled by the all-reduce)
+    const float* all1 = t->ar_fn ? c.s->bnsums_all : own1;
+    const float* all2 = t->ar_fn ? c.s->bnsums_all + 128 : own2;
+    f.bb1 = BnBwd{f.stats1, inv_rows, c.w(p.bn1.gamma), c.w(p.bn1.beta), all1, own1, c.g(p.bn1.gamma), c.g(p.bn1.beta)};
+    f.bb2 = BnBwd{f.stats2, inv_rows, c.w(p.bn2.gamma), c.w(p.bn2.beta), all2, own2, c.g(p.bn2.gamma), c.g(p.bn2.beta)};
+    f.bn1_sums = own1;
+    f.dx1 = c.s->dx1;
+    f.dz1 = c.s->dz1;
+    f.part = c.s->part;
+    f.n_sites = B;
+    f.S = tc.S;
+    f.ntiles = tc.ntiles;
+    f.step = seed;
+    f.stream_embed = (unsigned)(b * 8 + 0);
+    f.thr_embed = dropout_threshold(rt.embed);
+    f.scale_embed = rt.embed > 0.f ? 1.0f / (1.0f - rt.embed) : 1.0f;
+    f.stream_conv = (unsigned)(b * 8 + 1);
+    f.thr_conv = dropout_threshold(rt.conv);
+    f.scale_conv = rt.conv > 0.f ? 1.0f / (1.0f - rt.conv) : 1.0f;
+    return f;
+}
+
+BnFwd bn2_fwd(const Ctx& c, int b, int64_t B) {
+    dptm_trainer* t = c.t;
+    const BranchP& p = t->pm.br[b];
+    return BnFwd{t->bn_slots + (size_t)p.bn2.slot * 1024, 1.0f / (float)global_rows(t, B * t->ba[b].wlen), c.w(p.bn2.gamma),
+                 c.w(p.bn2.beta), c.g(p.bn2.mean), c.g(p.bn2.var)};
+}
+
+// One sequence branch forward (model.py:157-182) in three launches; the cuts sit where a BatchNorm needs the
+// statistics of the whole batch (and, with synchronised BatchNorm, of all replicas).
+int branch_fwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigned* seed, const Rates& rt) {
+    dptm_trainer* t = c.t;
+    BranchAct& a = t->ba[b];
     const int wl = a.wlen;
-    const int64_t R = B * wl, R64 = R * 64;
+    const TileCfg tc = t_tile_cfg(B, wl);
+    const ConvArgs cf = conv_args(c, b, tok, B, seed, rt, tc);
     int rc;
-    T_TRY(t_embed_fwd(tok, c.w(p.emb), c.w(p.pos), a.x0, R, wl, c.st));
-    T_TRY(t_dropout(a.x0, R, 64, 64, wl, seed, b * 8 + 0, rt.embed, c.st));
-    if ((rc = conv_fwd(c, a.x0, p.sck, p.scb, 1, a.s, R, wl))) return rc;
-    if ((rc = conv_fwd(c, a.x0, p.c3ak, p.c3ab, 3, a.a1, R, wl, a.y1))) return rc;       // y1 = swish(a1) in the epilogue
-    if ((rc = bn_train_fwd(c, a.y1, a.z1, 64, 0, R, 64, p.bn1, a.mi1))) return rc;
-    T_TRY(t_dropout(a.z1, R, 64, 64, wl, seed, b * 8 + 1, rt.conv, c.st));
-    if ((rc = conv_fwd(c, a.z1, p.c3bk, p.c3bb, 3, a.a2, R, wl, a.y2))) return rc;
-    if ((rc = bn_train_fwd(c, a.y2, a.x1, 64, 0, R, 64, p.bn2, a.mi2))) return rc;
-    T_TRY(t_add(a.x1, a.s, R64, c.st));
+    T_TRY(t_conv_a_fwd(cf, wl, tc.NW, c.st));
+    if ((rc = replica_sum(c, cf.stats1, 128))) return rc;
+    T_TRY(t_conv_b_fwd(cf, wl, tc.NW, c.st));
+    if ((rc = replica_sum(c, cf.stats2, 128))) return rc;
     {
-        // both TransformerBlocks and the attention pooling in one launch (model.py:172-182)
-        const TileCfg tc = t_tile_cfg(B, wl);
+        // BN2 + shortcut add, both TransformerBlocks and the attention pooling (model.py:138-141, 172-182)
         TbFwdArgs f;
-        f.P = reinterpret_cast<const f32x4_tr*>(t->P + t->img_fwd[b]);
-        f.x1 = a.x1;
+        f.P = cf.P;
+        f.cs = a.cs;
+        f.bn2 = bn2_fwd(c, b, B);
         f.sv[0] = a.sv[0];
         f.sv[1] = a.sv[1];
         f.pool = a.pool;
@@ -366,32 +385,30 @@ int branch_fwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
     return DPTM_OK;
 }
 
-// dpool = d(concat)[:, b*64 .. +64]  ->  all parameter gradients of branch b
+// d(concat)[:, b*64 .. +64]  ->  all parameter gradients of branch b, in three launches (+ the partial-sum kernels)
 int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigned* seed, const Rates& rt) {
     dptm_trainer* t = c.t;
     BranchAct& a = t->ba[b];
     const BranchP& p = t->pm.br[b];
     const int wl = a.wlen;
-    const int64_t R = B * wl, R64 = R * 64;
+    const TileCfg tc = t_tile_cfg(B, wl);
+    const ConvArgs cf = conv_args(c, b, tok, B, seed, rt, tc);
     int rc;
-    float* dx = c.s->g64a;      // gradient w.r.t. the block output / running d(x)
-    float* dsum = c.s->g64b;
-    float* tmp = c.s->g64c;
-    float* dh = c.s->g64d;
     {
-        // pooling and both TransformerBlocks backward in one launch: d(concat columns of this branch) -> dx = d(x1)
-        const TileCfg tc = t_tile_cfg(B, wl);
+        // pooling and both TransformerBlocks backward: d(concat columns of this branch) -> d(x1), BN2 column sums
         TbBwdArgs f;
-        f.P = reinterpret_cast<const f32x4_tr*>(t->P + t->img_fwd[b]);
-        f.PT = reinterpret_cast<const f32x4_tr*>(t->P + t->img_bwd[b]);
-        f.x1 = a.x1;
+        f.P = cf.P;
+        f.PT = cf.PT;
+        f.cs = a.cs;
+        f.bn2 = bn2_fwd(c, b, B);
+        f.bn2_sums = t->bn_slots + (size_t)(kBnLayers + p.bn2.slot) * 1024;
         f.sv[0] = a.sv[0];
         f.sv[1] = a.sv[1];
         f.pool = a.pool;
         f.dout = t->dconcat;
         f.ldd = kConcat;
         f.col_off = b * 64;
-        f.dx1 = dx;
+        f.dx1 = c.s->dx1;
         f.part = c.s->part;
         f.n_sites = B;
         f.S = tc.S;
@@ -412,18 +429,18 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
         g.poolb = c.g(p.poolb);
         T_TRY(t_tb_bwd(f, g, wl, tc.NW, c.st));
     }
-    // conv block: x1 = BN2(swish(conv3b(z1))) + conv1(x0); dx = d(x1)
-    // BatchNorm 2 -> dY2 (tmp) -> dA2 (tmp)
-    if ((rc = bn_train_bwd(c, dx, 64, 0, a.y2, tmp, R, 64, a.mi2, p.bn2))) return rc;
-    T_TRY(t_swish_bwd(a.a2, tmp, tmp, R64, c.st));
-    if ((rc = conv_bwd(c, a.z1, tmp, p.c3bk, p.c3bb, 3, dsum, false, R, wl))) return rc;     // dsum = dZ1 (after dropout)
-    T_TRY(t_dropout(dsum, R, 64, 64, wl, seed, b * 8 + 1, rt.conv, c.st));
-    if ((rc = bn_train_bwd(c, dsum, 64, 0, a.y1, tmp, R, 64, a.mi1, p.bn1))) return rc;
-    T_TRY(t_swish_bwd(a.a1, tmp, tmp, R64, c.st));                                          // dA1
-    if ((rc = conv_bwd(c, a.x0, tmp, p.c3ak, p.c3ab, 3, dh, false, R, wl))) return rc;       // dh = dX0 from conv3a
-    if ((rc = conv_bwd(c, a.x0, dx, p.sck, p.scb, 1, dh, true, R, wl))) return rc;           // += shortcut path
-    T_TRY(t_dropout(dh, R, 64, 64, wl, seed, b * 8 + 0, rt.embed, c.st));
-    T_TRY(t_embed_bwd(tok, dh, c.g(p.emb), c.g(p.pos), R, wl, c.st));
+    const ConvGrads cg{c.g(p.emb), c.g(p.pos), c.g(p.sck), c.g(p.scb), c.g(p.c3ak), c.g(p.c3ab), c.g(p.c3bk), c.g(p.c3bb)};
+    // the input gradient of a BatchNorm needs the sums over the WHOLE batch, its parameter gradients this replica's share
+    if (t->ar_fn) {
+        T_TRY(hipMemcpyAsync(c.s->bnsums_all + 128, cf.bb2.own, 128 * sizeof(float), hipMemcpyDeviceToDevice, c.st));
+        if ((rc = replica_sum(c, c.s->bnsums_all + 128, 128))) return rc;
+    }
+    T_TRY(t_conv_b_bwd(cf, cg, wl, tc.NW, c.st));
+    if (t->ar_fn) {
+        T_TRY(hipMemcpyAsync(c.s->bnsums_all, cf.bb1.own, 128 * sizeof(float), hipMemcpyDeviceToDevice, c.st));
+        if ((rc = replica_sum(c, c.s->bnsums_all, 128))) return rc;
+    }
+    T_TRY(t_conv_a_bwd(cf, cg, wl, tc.NW, c.st));
     return DPTM_OK;
 }
 
@@ -532,7 +549,7 @@ int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spe
         for (int b = 0; b < 3; ++b) {
             const BranchP& q = t->pm.br[b];
             const int64_t F = t->img_fwd[b] = reserve((int64_t)kBranchF4 * 4);
-            const int64_t T = t->img_bwd[b] = reserve((int64_t)2 * kBtSize * 4);
+            const int64_t T = t->img_bwd[b] = reserve((int64_t)kBtTotal * 4);
             auto mat = [&](int tensor, int64_t src_off, int64_t dst_f4, int K, int N, bool tr, int64_t base) {
                 pend.push_back(Pending{tensor, src_off, base + dst_f4 * 4, 0, K, N, tr ? 1 : 0});
             };
@@ -570,6 +587,11 @@ int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spe
             }
             vec(q.poolk, kOffPoolV, kD);
             copy(q.poolb, kOffPoolB, 1);
+            mat(q.sck, 0, kBtScT, kD, kD, true, T);
+            for (int tap = 0; tap < 3; ++tap) {
+                mat(q.c3ak, (int64_t)tap * kD * kD, kBtC3aT + tap * 1024, kD, kD, true, T);
+                mat(q.c3bk, (int64_t)tap * kD * kD, kBtC3bT + tap * 1024, kD, kD, true, T);
+            }
         }
         if (hipMalloc((void**)&t->P, (size_t)off * sizeof(float)) != hipSuccess ||
             hipMalloc((void**)&t->pack_jobs, pend.size() * sizeof(PackJob)) != hipSuccess)

@@ -25,8 +25,10 @@
 #include "dptm_attend.h"
 #include "dptm_layout.h"
 #include "dptm_mfma.h"
+#include "dptm_phase.h"
 #include "dptm_train_device.h"
 #include "dptm_train_kernels.h"
+#include "dptm_train_tile.h"
 
 namespace dptm {
 
@@ -113,169 +115,6 @@ int64_t t_tile_rows_max(int64_t max_sites, int wlen) {
     return best;
 }
 
-// ------------------------------------------------------------------------------------ device helpers
-
-template <int NT>
-__device__ __forceinline__ void acc_zero(f32x16 (&acc)[NT]) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-}
-
-// inverse of acc_to_x: accumulator tiles that start from a chain-layout vector
-__device__ __forceinline__ void x_to_acc(const f32x4 (&x)[8], f32x16 (&acc)[2]) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[t][4 * g + e] = x[4 * t + g][e];
-}
-
-// chain-layout row vector <-> the lane's row of an LDS image [rows][kLdsStride]
-__device__ __forceinline__ void chain_store(float* row_base, int h, const f32x4 (&x)[8]) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x4*>(row_base + 8 * u + 4 * h) = x[u];
-}
-
-// sum over 32 image rows of column `lane` (lane = feature)
-__device__ __forceinline__ float colsum32(const float* img_rows, int lane) {
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int r = 0; r < 32; r += 2) {
-        s0 += img_rows[r * kLdsStride + lane];
-        s1 += img_rows[(r + 1) * kLdsStride + lane];
-    }
-    return s0 + s1;
-}
-
-// inverted dropout of a chain-layout row vector; the element index of (row r, feature c) is r*64 + c, as in the
-// layer-wise dropout kernels and the NumPy restatement, so every implementation sees the same mask
-__device__ __forceinline__ void dropout_chain(f32x4 (&x)[8], int64_t r, int h, unsigned seed, unsigned stream, unsigned thr,
-                                              float scale) {
-    if (thr == 0u) return;
-    const unsigned base = (unsigned)(r * 64) + 4 * h;
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) x[u][e] = hash_u32(seed, stream, base + 8 * u + e) >= thr ? x[u][e] * scale : 0.f;
-}
-
-// acc[t] += (rows 64c .. 64c+63 of a packed [256][64] matrix)^T-product with a 64-feature chain vector: the K = 256
-// image has 32 feature groups per out tile, the chunk owns groups 8c .. 8c+7
-__device__ __forceinline__ void gemm_k256_chunk(f32x16 (&acc)[2], const f32x4* __restrict__ wp, int c, const f32x4 (&x)[8],
-                                                int lane) {
-    f32x4 a[8][2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) a[u][t] = wp[(t * 32 + 8 * c + u) * 64 + lane];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        if (u + 2 < 8) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) a[u + 2][t] = wp[(t * 32 + 8 * c + u + 2) * 64 + lane];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) mfma(acc[t], a[u][t][e], x[u][e]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// Chain layout -> the lane's two heads: lane (h, j) gets heads 2h and 2h+1 of row j, 16 features each in natural
-// order (one exchange between the half-waves per register pair), times `scale`.
-__device__ __forceinline__ void x_to_heads(const f32x4 (&x)[8], float (&hd)[2][16], float scale) {
-    float qa[16], qb[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        qa[r] = x[r >> 2][r & 3] * scale;
-        qb[r] = x[4 + (r >> 2)][r & 3] * scale;
-        half_swap(qa[r], qb[r]);
-    }
-#pragma unroll
-    for (int d = 0; d < 16; ++d) {
-        const int src = 4 * (d >> 3) + (d & 3);
-        hd[0][d] = (d & 4) ? qb[src] : qa[src];
-        hd[1][d] = (d & 4) ? qb[8 + src] : qa[8 + src];
-    }
-}
-__device__ __forceinline__ void heads_to_x(const float (&hd)[2][16], f32x4 (&x)[8], float scale) {
-    float qa[16], qb[16];
-#pragma unroll
-    for (int d = 0; d < 16; ++d) {
-        const int dst = 4 * (d >> 3) + (d & 3);
-        if (d & 4) {
-            qb[dst] = hd[0][d] * scale;
-            qb[8 + dst] = hd[1][d] * scale;
-        } else {
-            qa[dst] = hd[0][d] * scale;
-            qa[8 + dst] = hd[1][d] * scale;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        half_swap(qa[r], qb[r]);
-        x[r >> 2][r & 3] = qa[r];
-        x[4 + (r >> 2)][r & 3] = qb[r];
-    }
-}
-
-// keras LayerNormalization(epsilon=1e-6): y (the summed input) becomes xhat; returns 1/sigma
-__device__ __forceinline__ float ln_normalise(f32x4 (&y)[8]) {
-    float s = 0.f;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += (y[u][0] + y[u][1]) + (y[u][2] + y[u][3]);
-    const float mean = xhalf_sum(s) * (1.0f / 64.0f);
-    float q = 0.f;
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float d = y[u][e] - mean;
-            y[u][e] = d;
-            q = fmaf(d, d, q);
-        }
-    const float inv = rsqrtf(xhalf_sum(q) * (1.0f / 64.0f) + 1e-6f);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) y[u] *= inv;
-    return inv;
-}
-
-// out = xhat * gamma + beta with packed vectors (float4 index h*8 + u)
-__device__ __forceinline__ void ln_affine(const f32x4 (&xh)[8], const f32x4* __restrict__ g, const f32x4* __restrict__ b, int h,
-                                          f32x4 (&out)[8]) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) out[u] = xh[u] * g[h * 8 + u] + b[h * 8 + u];
-}
-
-// Backward of LayerNormalization for the lane's row: dy -> dsum = inv * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)).
-// The parameter gradients need column sums over rows: dy * xhat goes to the lane's row of imgA and dy to imgB (the
-// wavefront's own 32 rows of two idle images), from where colsum32 takes them.
-__device__ __forceinline__ void ln_backward(const f32x4 (&dy)[8], const f32x4 (&xh)[8], float inv, const f32x4* __restrict__ g,
-                                            int h, f32x4 (&dsum)[8], float* rowA, float* rowB) {
-    float s1 = 0.f, s2 = 0.f;
-    f32x4 t[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        t[u] = dy[u] * xh[u];
-        dsum[u] = dy[u] * g[h * 8 + u];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            s1 += dsum[u][e];
-            s2 = fmaf(dsum[u][e], xh[u][e], s2);
-        }
-    }
-    chain_store(rowA, h, t);
-    chain_store(rowB, h, dy);
-    s1 = xhalf_sum(s1) * (1.0f / 64.0f);
-    s2 = xhalf_sum(s2) * (1.0f / 64.0f);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) dsum[u] = inv * (dsum[u] - s1 - xh[u] * s2);
-}
-
 // ------------------------------------------------------------------------------------ forward
 
 template <int W>
@@ -286,6 +125,7 @@ __global__ __launch_bounds__(512) void tb_fwd_kernel(TbFwdArgs p) {
     float* bufB = bufA + rows_tile * kLdsStride;
     float* score = bufB + rows_tile * kLdsStride;   // [rows_tile] exp(tanh score)
     float* alpha_s = score + rows_tile;             // [rows_tile] pooling weights
+    float* bnv = alpha_s + rows_tile;               // [scale | shift] of the second BatchNorm
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, j = lane & 31;
     const unsigned seed = p.step[kStepSeed];
@@ -294,6 +134,8 @@ __global__ __launch_bounds__(512) void tb_fwd_kernel(TbFwdArgs p) {
     float* mine_a = bufA + row * kLdsStride;
     float* mine_b = bufB + row * kLdsStride;
     const int att_start = min(row / W, S - 1) * W;
+    bn_prepare(p.bn2, bnv, tid, blockIdx.x == 0);
+    __syncthreads();
 #pragma unroll 1
     for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int64_t site0 = tile * S;
@@ -304,11 +146,7 @@ __global__ __launch_bounds__(512) void tb_fwd_kernel(TbFwdArgs p) {
         const int64_t ct = ((tile * NW + wave) * 8) * 64 + lane;
         const int64_t cl = (tile * NW + wave) * 64 + lane;
         f32x4 x1[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            x1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (row_ok) x1[u] = *reinterpret_cast<const f32x4*>(p.x1 + grow * 64 + 8 * u + 4 * h);
-        }
+        x1_from_conv(p.cs, ct, bnv, h, row_ok, x1);
 #pragma unroll 1
         for (int blk = 0; blk < 2; ++blk) {
             const f32x4* T = p.P + kOffTb + blk * kTbSize;
@@ -448,61 +286,6 @@ __global__ __launch_bounds__(512) void tb_fwd_kernel(TbFwdArgs p) {
 
 // ------------------------------------------------------------------------------------ backward
 
-// One 64 x 64 weight-gradient unit: part_u (+)= X^T Y over the rows of the tile, X and Y being LDS images.  The
-// caller has put a barrier between writing the images and this call; the call ends with one barrier, after which
-// the images (not xchg) may be overwritten.  xchg: 4096 floats of LDS that nothing else uses across the call.
-// part_u: this workgroup's 4096 floats for the unit, accumulator order [block][register][lane].
-__device__ __forceinline__ void dw_unit(const float* imgX, const float* imgY, int NW, float* xchg, float* __restrict__ part_u,
-                                        bool first, int lane, int wave) {
-    const int hh = lane >> 5, i = lane & 31;
-    if (NW >= 4) {
-        // wavefront w: block w & 3 over row half w >> 2 (NW = 4: one "half" of all 128 rows)
-        const int b = wave & 3, sp = wave >> 2;
-        const float* ap = imgX + (sp * 128 + hh) * kLdsStride + 32 * (b >> 1) + i;
-        const float* bp = imgY + (sp * 128 + hh) * kLdsStride + 32 * (b & 1) + i;
-        float* dst = part_u + b * 1024 + lane;
-        f32x16 acc;
-#pragma unroll
-        for (int rg = 0; rg < 16; ++rg) acc[rg] = 0.f;
-        if (sp == 0 && !first) {
-#pragma unroll
-            for (int rg = 0; rg < 16; ++rg) acc[rg] = dst[rg * 64];
-        }
-#pragma unroll 8
-        for (int q = 0; q < 64; ++q) mfma(acc, ap[2 * q * kLdsStride], bp[2 * q * kLdsStride]);
-        if (sp == 1) {
-#pragma unroll
-            for (int rg = 0; rg < 16; ++rg) xchg[(b * 16 + rg) * 64 + lane] = acc[rg];
-        }
-        __syncthreads();
-        if (sp == 0) {
-            if (NW == 8) {
-#pragma unroll
-                for (int rg = 0; rg < 16; ++rg) acc[rg] += xchg[(b * 16 + rg) * 64 + lane];
-            }
-#pragma unroll
-            for (int rg = 0; rg < 16; ++rg) dst[rg * 64] = acc[rg];
-        }
-    } else {
-        // one or two wavefronts: 4 / NW blocks each over all rows
-        const int bpw = 4 / NW, steps = NW * 16;
-        for (int bi = 0; bi < bpw; ++bi) {
-            const int b = wave * bpw + bi;
-            const float* ap = imgX + hh * kLdsStride + 32 * (b >> 1) + i;
-            const float* bp = imgY + hh * kLdsStride + 32 * (b & 1) + i;
-            float* dst = part_u + b * 1024 + lane;
-            f32x16 acc;
-#pragma unroll
-            for (int rg = 0; rg < 16; ++rg) acc[rg] = first ? 0.f : dst[rg * 64];
-#pragma unroll 8
-            for (int q = 0; q < steps; ++q) mfma(acc, ap[2 * q * kLdsStride], bp[2 * q * kLdsStride]);
-#pragma unroll
-            for (int rg = 0; rg < 16; ++rg) dst[rg * 64] = acc[rg];
-        }
-        __syncthreads();
-    }
-}
-
 // attention backward, lane = query row, one head: dq = sum_t dz_t k_t with dz_t = p_t (dO.v_t - D),
 // p_t = exp2(q.k_t - m) * rden (q scaled by log2(e)/4 as in the forward pass)
 template <int W>
@@ -588,12 +371,12 @@ __device__ __forceinline__ void attn_bwd_kv(const float* qp, const float* dop, c
         }
 }
 
-constexpr int kXreg = 4096;                        // floats: exchange buffer of dw_unit / softmax statistics / pooling scores
 constexpr float kLn2 = 0.69314718055994530942f;
 
 // index of a block's vectors in the partial buffer
 enum TbVecSlot { kSG2 = 0, kSB2, kSFb2, kSFb1, kSG1 = kSFb1 + 4, kSB1, kSBo, kSBq, kSBk, kSBv, kSlotsPerBlock = 14 };
 constexpr int kSPoolW = 2 * kSlotsPerBlock, kSPoolB = kSPoolW + 1;
+constexpr int kSBn2A = 13, kSBn2B = 27;     // the two spare slots: sum d(x1), sum d(x1) * swish(a2)
 static_assert(kSPoolB < kTbVecs, "vector slots");
 
 template <int W>
@@ -604,6 +387,7 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
     float* bufB = bufA + rows_tile * kLdsStride;
     float* xreg = bufB + rows_tile * kLdsStride;
     float* vacc = xreg + kXreg;                     // [kTbVecs][64] column sums of this workgroup
+    float* bnv = vacc + kTbVecs * 64;               // [scale | shift] of the second BatchNorm
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, j = lane & 31;
     const unsigned seed = p.step[kStepSeed];
@@ -616,8 +400,10 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
     const int att_start = min(row / W, S - 1) * W;
     float* part = p.part + (size_t)blockIdx.x * kTbPartStride;
     for (int i = tid; i < kTbVecs * 64; i += blockDim.x) vacc[i] = 0.f;
+    bn_prepare(p.bn2, bnv, tid, false);
     __syncthreads();
     bool first = true;
+    PH_DECL
 #pragma unroll 1
     for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
         const int64_t site0 = tile * S;
@@ -672,6 +458,7 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
             wave_fence();
             __syncthreads();   // the scores in xreg have been read
         }
+        PH_MARK(0)   // pooling backward
 #pragma unroll 1
         for (int blk = 1; blk >= 0; --blk) {
             const f32x4* T = p.P + kOffTb + blk * kTbSize;
@@ -693,6 +480,7 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                 atomicAdd(va + kSB2 * 64, colsum32(own_b, lane));
                 wave_fence();
             }
+            PH_MARK(1)   // LayerNorm 2 backward
             f32x4 df2[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) df2[u] = dsum[u];
@@ -727,6 +515,7 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                         }
                     chain_store(mine_a, h, u_);
                 }
+                PH_MARK(2)   // feed-forward row products
                 chain_store(mine_b, h, df2);
                 if (c == 0) {
                     wave_fence();
@@ -734,6 +523,7 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                 }
                 __syncthreads();
                 dw_unit(bufA, bufB, NW, xreg, pu + (4 + c) * 4096, first, lane, wave);     // dW2[chunk, :] += u_c^T d(f2)
+                PH_MARK(3)   // feed-forward weight gradients
                 f32x4 d1[8];
                 {
                     f32x16 acc_u[2];
@@ -743,14 +533,17 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) d1[u] *= g[u];                             // d(f1_c)
                 }
+                PH_MARK(2)
                 chain_store(mine_a, h, hx);
                 chain_store(mine_b, h, d1);
                 wave_fence();
                 atomicAdd(va + (kSFb1 + c) * 64, colsum32(own_b, lane));
                 __syncthreads();
                 dw_unit(bufA, bufB, NW, xreg, pu + c * 4096, first, lane, wave);           // dW1[:, chunk] += h^T d(f1_c)
+                PH_MARK(3)
                 gemm_k256_chunk(acc_dh, TT + kBtW1T, c, d1, lane);                         // d(h) += d(f1_c) W1[:, chunk]^T
             }
+            PH_MARK(2)
             // ---- LayerNorm 1 backward: d(h) -> dsum = d(x + ao)
             {
                 f32x4 dh[8], xh[8];
@@ -763,10 +556,12 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                 atomicAdd(va + kSB1 * 64, colsum32(own_b, lane));
                 wave_fence();
             }
+            PH_MARK(4)   // LayerNorm 1 backward
             // ---- output projection backward
-            f32x4 o[8], dO[8];
+            f32x4 dO[8];
+            float D[2];        // D = dO . o per head (= sum_t p_t dO.v_t), heads 2h and 2h+1 of the lane's row
             {
-                f32x4 dao[8];
+                f32x4 dao[8], o[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     dao[u] = dsum[u];
@@ -783,47 +578,76 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                 acc_zero<2>(acc);
                 gemm_regs<8, 2>(acc, TT + kBtWoT, dao, lane);                              // d(o) = d(ao) Wo^T
                 acc_to_x<2>(acc, dO);
+                // head hd owns feature groups 2hd, 2hd+1; each half-wave holds half of every group
+                float d4[4];
+#pragma unroll
+                for (int hd = 0; hd < 4; ++hd) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s = fmaf(dO[2 * hd][e], o[2 * hd][e], fmaf(dO[2 * hd + 1][e], o[2 * hd + 1][e], s));
+                    d4[hd] = xhalf_sum(s);
+                }
+                D[0] = h ? d4[2] : d4[0];
+                D[1] = h ? d4[3] : d4[1];
             }
-            // ---- attention backward
-            f32x4 dq[8], dk[8], dv[8];
+            PH_MARK(5)   // output projection backward
+            const f32x4 st = sv.stat[cl];
+            f32x16 acc_dx[2];   // d(x) = dsum + dq Wq^T + dk Wk^T + dv Wv^T, summed as the terms appear
+            // ---- attention backward, lane = query row: dq
             {
-                f32x4 qx[8], kx[8], vx[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    qx[u] = sv.q[ct + u * 64];
-                    kx[u] = sv.k[ct + u * 64];
-                    vx[u] = sv.v[ct + u * 64];
-                }
-                chain_store(mine_a, h, kx);
-                chain_store(mine_b, h, vx);
-                float qs[2][16], doh[2][16], D[2];
-                x_to_heads(qx, qs, kQScale);
-                x_to_heads(dO, doh, 1.0f);
-                {
-                    float oh[2][16];
-                    x_to_heads(o, oh, 1.0f);
-#pragma unroll
-                    for (int hd = 0; hd < 2; ++hd) {
-                        float s = 0.f;
-#pragma unroll
-                        for (int d = 0; d < 16; ++d) s = fmaf(doh[hd][d], oh[hd][d], s);
-                        D[hd] = s;
-                    }
-                }
-                const f32x4 st = sv.stat[cl];
-                __syncthreads();   // K and V of the tile are in LDS
-                float gh[2][16];
-#pragma unroll
-                for (int hd = 0; hd < 2; ++hd) {
-                    const int off = att_start * kLdsStride + 32 * h + 16 * hd;
-                    attn_bwd_q<W>(bufA + off, bufB + off, qs[hd], doh[hd], st[2 * hd], st[2 * hd + 1], D[hd], gh[hd]);
-                }
-                heads_to_x(gh, dq, 0.25f);
-                __syncthreads();   // K and V have been read
+                f32x4 dq[8];
                 {
                     f32x4 t[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = qx[u] * kQScale;
+                    for (int u = 0; u < 8; ++u) t[u] = sv.k[ct + u * 64];
+                    chain_store(mine_a, h, t);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] = sv.v[ct + u * 64];
+                    chain_store(mine_b, h, t);
+                    float qs[2][16], doh[2][16], gh[2][16];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] = sv.q[ct + u * 64];
+                    x_to_heads(t, qs, kQScale);
+                    x_to_heads(dO, doh, 1.0f);
+                    __syncthreads();   // K and V of the tile are in LDS
+#pragma unroll
+                    for (int hd = 0; hd < 2; ++hd) {
+                        const int off = att_start * kLdsStride + 32 * h + 16 * hd;
+                        attn_bwd_q<W>(bufA + off, bufB + off, qs[hd], doh[hd], st[2 * hd], st[2 * hd + 1], D[hd], gh[hd]);
+                    }
+                    heads_to_x(gh, dq, row_ok ? 0.25f : 0.f);
+                }
+                PH_MARK(6)   // attention backward, query rows
+                __syncthreads();   // K and V have been read
+                PH_MARK(10)  // barrier after a vector-unit phase
+                {
+                    f32x4 xin[8];
+                    if (blk == 0) {
+                        x1_from_conv(p.cs, ct, bnv, h, row_ok, xin);
+                    } else {
+                        const f32x4* tv0 = p.P + kOffTb + kTbVec;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) xin[u] = p.sv[0].xh2[ct + u * 64];
+                        ln_affine(xin, tv0 + kVLn2G * kVec64, tv0 + kVLn2B * kVec64, h, xin);
+                    }
+                    chain_store(mine_a, h, xin);
+                }
+                chain_store(mine_b, h, dq);
+                wave_fence();
+                atomicAdd(va + kSBq * 64, colsum32(own_b, lane));
+                __syncthreads();
+                dw_unit(bufA, bufB, NW, xreg, pu + 9 * 4096, first, lane, wave);           // dWq += x^T dq
+                x_to_acc(dsum, acc_dx);
+                gemm_regs<8, 2>(acc_dx, TT + kBtWqT, dq, lane);
+            }
+            PH_MARK(7)   // Q / K / V projections backward
+            // ---- attention backward, lane = key row: dk, dv
+            {
+                f32x4 dk[8], dv[8];
+                {
+                    f32x4 t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) t[u] = sv.q[ct + u * 64] * kQScale;
                     chain_store(mine_a, h, t);
                     chain_store(mine_b, h, dO);
 #pragma unroll
@@ -832,89 +656,90 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                         xreg[rows_tile * 4 + row * 4 + 2 * h + hd] = st[2 * hd + 1];
                         xreg[2 * rows_tile * 4 + row * 4 + 2 * h + hd] = D[hd];
                     }
-                }
-                __syncthreads();   // scaled Q, dO and the statistics of the tile are in LDS
-                float kh[2][16], vh[2][16], gk[2][16], gv[2][16];
-                x_to_heads(kx, kh, 1.0f);
-                x_to_heads(vx, vh, 1.0f);
+                    float kh[2][16], vh[2][16], gk[2][16], gv[2][16];
 #pragma unroll
-                for (int hd = 0; hd < 2; ++hd) {
-                    const int off = att_start * kLdsStride + 32 * h + 16 * hd;
-                    attn_bwd_kv<W>(bufA + off, bufB + off, xreg + att_start * 4 + 2 * h + hd, rows_tile * 4, kh[hd], vh[hd], gk[hd],
-                                   gv[hd]);
-                }
-                heads_to_x(gk, dk, kLn2);
-                heads_to_x(gv, dv, 1.0f);
-                if (!row_ok) {
+                    for (int u = 0; u < 8; ++u) t[u] = sv.k[ct + u * 64];
+                    x_to_heads(t, kh, 1.0f);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) dq[u] = dk[u] = dv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-                __syncthreads();   // Q and dO have been read
-            }
-            // ---- Q / K / V projections backward: weight gradients from the block input, then d(x)
-            {
-                f32x4 xin[8];
-                if (blk == 0) {
+                    for (int u = 0; u < 8; ++u) t[u] = sv.v[ct + u * 64];
+                    x_to_heads(t, vh, 1.0f);
+                    __syncthreads();   // scaled Q, dO and the statistics of the tile are in LDS
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        xin[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (row_ok) xin[u] = *reinterpret_cast<const f32x4*>(p.x1 + grow * 64 + 8 * u + 4 * h);
+                    for (int hd = 0; hd < 2; ++hd) {
+                        const int off = att_start * kLdsStride + 32 * h + 16 * hd;
+                        attn_bwd_kv<W>(bufA + off, bufB + off, xreg + att_start * 4 + 2 * h + hd, rows_tile * 4, kh[hd], vh[hd], gk[hd],
+                                       gv[hd]);
                     }
-                } else {
-                    const f32x4* tv0 = p.P + kOffTb + kTbVec;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) xin[u] = p.sv[0].xh2[ct + u * 64];
-                    ln_affine(xin, tv0 + kVLn2G * kVec64, tv0 + kVLn2B * kVec64, h, xin);
+                    heads_to_x(gk, dk, row_ok ? kLn2 : 0.f);
+                    heads_to_x(gv, dv, row_ok ? 1.0f : 0.f);
                 }
-                chain_store(mine_a, h, xin);
-            }
-            chain_store(mine_b, h, dq);
-            wave_fence();
-            atomicAdd(va + kSBq * 64, colsum32(own_b, lane));
-            __syncthreads();
-            dw_unit(bufA, bufB, NW, xreg, pu + 9 * 4096, first, lane, wave);
-            chain_store(mine_b, h, dk);
-            wave_fence();
-            atomicAdd(va + kSBk * 64, colsum32(own_b, lane));
-            __syncthreads();
-            dw_unit(bufA, bufB, NW, xreg, pu + 10 * 4096, first, lane, wave);
-            chain_store(mine_b, h, dv);
-            wave_fence();
-            atomicAdd(va + kSBv * 64, colsum32(own_b, lane));
-            __syncthreads();
-            dw_unit(bufA, bufB, NW, xreg, pu + 11 * 4096, first, lane, wave);
-            {
-                f32x16 acc[2];
-                x_to_acc(dsum, acc);
-                gemm_regs<8, 2>(acc, TT + kBtWqT, dq, lane);
-                gemm_regs<8, 2>(acc, TT + kBtWkT, dk, lane);
-                gemm_regs<8, 2>(acc, TT + kBtWvT, dv, lane);
-                acc_to_x<2>(acc, dy);
-            }
-        }
-        if (row_ok) {
+                PH_MARK(8)   // attention backward, key rows
+                __syncthreads();   // Q and dO have been read
+                PH_MARK(10)
+                {
+                    f32x4 xin[8];
+                    if (blk == 0) {
+                        x1_from_conv(p.cs, ct, bnv, h, row_ok, xin);
+                    } else {
+                        const f32x4* tv0 = p.P + kOffTb + kTbVec;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x4*>(p.dx1 + grow * 64 + 8 * u + 4 * h) = dy[u];
+                        for (int u = 0; u < 8; ++u) xin[u] = p.sv[0].xh2[ct + u * 64];
+                        ln_affine(xin, tv0 + kVLn2G * kVec64, tv0 + kVLn2B * kVec64, h, xin);
+                    }
+                    chain_store(mine_a, h, xin);
+                }
+                chain_store(mine_b, h, dk);
+                wave_fence();
+                atomicAdd(va + kSBk * 64, colsum32(own_b, lane));
+                __syncthreads();
+                dw_unit(bufA, bufB, NW, xreg, pu + 10 * 4096, first, lane, wave);          // dWk += x^T dk
+                gemm_regs<8, 2>(acc_dx, TT + kBtWkT, dk, lane);
+                chain_store(mine_b, h, dv);
+                wave_fence();
+                atomicAdd(va + kSBv * 64, colsum32(own_b, lane));
+                __syncthreads();
+                dw_unit(bufA, bufB, NW, xreg, pu + 11 * 4096, first, lane, wave);          // dWv += x^T dv
+                gemm_regs<8, 2>(acc_dx, TT + kBtWvT, dv, lane);
+            }
+            acc_to_x<2>(acc_dx, dy);
+            PH_MARK(7)
+        }
+        // d(x1) leaves chain-tiled; its column sums (with swish(a2)) feed the second BatchNorm's backward pass
+        {
+            f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                p.dx1[ct + u * 64] = dy[u];
+                const f32x4 a = p.cs.a2[ct + u * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[u][e] = dy[u][e] * swishf(a[e]);
+            }
+            chain_store(mine_a, h, dy);
+            chain_store(mine_b, h, t);
+            wave_fence();
+            atomicAdd(&vacc[kSBn2A * 64 + lane], colsum32(own_a, lane));
+            atomicAdd(&vacc[kSBn2B * 64 + lane], colsum32(own_b, lane));
+            wave_fence();
         }
         first = false;
     }
     __syncthreads();
-    for (int i = tid; i < kTbVecs * 64; i += blockDim.x) part[kTbUnits * 4096 + i] = vacc[i];
+    for (int i = tid; i < kTbVecs * 64; i += blockDim.x) {
+        const int slot = i >> 6;
+        if (slot == kSBn2A)
+            atomicAdd(p.bn2_sums + (i & 63), vacc[i]);
+        else if (slot == kSBn2B)
+            atomicAdd(p.bn2_sums + 64 + (i & 63), vacc[i]);
+        else
+            part[kTbUnits * 4096 + i] = vacc[i];
+    }
+    PH_FLUSH
 }
 
 // ------------------------------------------------------------------------------------ partial sums -> gradients
 
-struct UnitTab {
-    float* dst[kTbUnits];     // element (k, n) of unit u lives at dst[u][k*ld[u] + n]
-    int ld[kTbUnits];
-};
-struct VecTab {
-    float* dst[kTbVecs];
-    int len[kTbVecs];
-};
-
 // grid (16, units): thread o of a unit is accumulator element [block o>>10][register (o>>6)&15][lane o&63]
-__global__ __launch_bounds__(256) void reduce_units_kernel(const float* __restrict__ part, int nparts, UnitTab tab) {
+__global__ __launch_bounds__(256) void reduce_units_kernel(const float* __restrict__ part, int nparts, PartUnits tab) {
     const int u = blockIdx.y;
     const int o = blockIdx.x * 256 + threadIdx.x;
     const float* src = part + (size_t)u * 4096 + o;
@@ -930,37 +755,31 @@ __global__ __launch_bounds__(256) void reduce_units_kernel(const float* __restri
     tab.dst[u][(size_t)k * tab.ld[u] + n] += a0 + a1;
 }
 
-// grid (vectors): 64 threads
-__global__ __launch_bounds__(64) void reduce_vecs_kernel(const float* __restrict__ part, int nparts, VecTab tab) {
-    const int v = blockIdx.x, f = threadIdx.x;
+// grid (vectors, ceil(longest / 256))
+__global__ __launch_bounds__(256) void reduce_vecs_kernel(const float* __restrict__ part, int nparts, PartVecs tab) {
+    const int v = blockIdx.x, f = blockIdx.y * 256 + threadIdx.x;
     if (f >= tab.len[v]) return;
-    const float* src = part + (size_t)kTbUnits * 4096 + v * 64 + f;
+    const float* src = part + tab.off[v] + f;
     float a = 0.f;
     for (int pi = 0; pi < nparts; ++pi) a += src[(size_t)pi * kTbPartStride];
     tab.dst[v][f] += a;
 }
 
+hipError_t t_reduce_parts(const float* part, int nparts, const PartUnits& u, const PartVecs& v, hipStream_t st) {
+    if (u.n > 0) hipLaunchKernelGGL(reduce_units_kernel, dim3(16, (unsigned)u.n), dim3(256), 0, st, part, nparts, u);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    int longest = 0;
+    for (int i = 0; i < v.n; ++i) longest = v.len[i] > longest ? v.len[i] : longest;
+    if (v.n > 0 && longest > 0)
+        hipLaunchKernelGGL(reduce_vecs_kernel, dim3((unsigned)v.n, (unsigned)((longest + 255) / 256)), dim3(256), 0, st, part, nparts, v);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------ launchers
 
-static size_t fwd_lds(int NW) { return ((size_t)2 * NW * 32 * kLdsStride + 2 * NW * 32) * sizeof(float); }
-static size_t bwd_lds(int NW) { return ((size_t)2 * NW * 32 * kLdsStride + kXreg + kTbVecs * 64) * sizeof(float); }
-
-template <typename K>
-static hipError_t lds_opt_in(K kernel, bool (&done)[64], size_t bytes) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (done[dev]) return hipSuccess;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e == hipSuccess) done[dev] = true;
-    return e;
-}
-
-static bool tile_ok(int wlen, int S, int NW, int64_t n, int64_t ntiles) {
-    return (wlen == 21 || wlen == 33 || wlen == 51) && (NW == 1 || NW == 2 || NW == 4 || NW == 8) && S >= 1 && S * wlen <= NW * 32 &&
-           ntiles == (n + S - 1) / S;
-}
+static size_t fwd_lds(int NW) { return ((size_t)2 * NW * 32 * kLdsStride + 2 * NW * 32 + 128) * sizeof(float); }
+static size_t bwd_lds(int NW) { return ((size_t)2 * NW * 32 * kLdsStride + kXreg + kTbVecs * 64 + 128) * sizeof(float); }
 
 template <int W>
 static hipError_t launch_fwd(const TbFwdArgs& a, int NW, hipStream_t st) {
@@ -1002,8 +821,15 @@ hipError_t t_tb_bwd(const TbBwdArgs& a, const TbGrads& g, int wlen, int NW, hipS
         default: e = launch_bwd<51>(a, NW, grid, st); break;
     }
     if (e != hipSuccess) return e;
-    UnitTab ut;
-    VecTab vt;
+    PartUnits ut;
+    PartVecs vt;
+    ut.n = kTbUnits;
+    vt.n = kTbVecs;
+    for (int i = 0; i < kTbVecs; ++i) {
+        vt.off[i] = kTbUnits * 4096 + i * 64;
+        vt.len[i] = 64;
+        vt.dst[i] = nullptr;
+    }
     for (int b = 0; b < 2; ++b) {
         for (int c = 0; c < 4; ++c) {
             ut.dst[b * 12 + c] = g.w1[b] + 64 * c;              // dW1[:, 64c ..]  (raw [64][256])
@@ -1017,21 +843,17 @@ hipError_t t_tb_bwd(const TbBwdArgs& a, const TbGrads& g, int wlen, int NW, hipS
             ut.ld[b * 12 + 8 + i] = 64;
         }
         float** vd = vt.dst + b * kSlotsPerBlock;
-        int* vl = vt.len + b * kSlotsPerBlock;
-        for (int i = 0; i < kSlotsPerBlock; ++i) vl[i] = 64;
         vd[kSG2] = g.ln2g[b]; vd[kSB2] = g.ln2b[b]; vd[kSFb2] = g.b2[b];
         for (int c = 0; c < 4; ++c) vd[kSFb1 + c] = g.b1[b] + 64 * c;
         vd[kSG1] = g.ln1g[b]; vd[kSB1] = g.ln1b[b]; vd[kSBo] = g.bo[b];
         vd[kSBq] = g.bq[b]; vd[kSBk] = g.bk[b]; vd[kSBv] = g.bv[b];
-        vd[13] = g.bv[b];
-        vl[13] = 0;
+        vt.len[b * kSlotsPerBlock + 13] = 0;      // spare slot: those column sums leave through atomics
     }
-    vt.dst[kSPoolW] = g.poolw; vt.len[kSPoolW] = 64;
+    vt.dst[kSPoolW] = g.poolw;
     vt.dst[kSPoolB] = g.poolb; vt.len[kSPoolB] = 1;
-    hipLaunchKernelGGL(reduce_units_kernel, dim3(16, kTbUnits), dim3(256), 0, st, a.part, grid, ut);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(reduce_vecs_kernel, dim3(kTbVecs), dim3(64), 0, st, a.part, grid, vt);
-    return hipGetLastError();
+    return t_reduce_parts(a.part, grid, ut, vt, st);
 }
 
 }  // namespace dptm
+
+PH_DEFINE_READER(dptm_debug_phase_cycles_train)

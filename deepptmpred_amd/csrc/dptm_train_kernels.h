@@ -144,9 +144,36 @@ struct TbSave {
     f32x2_tr* inv;         // 1/sigma of the two LayerNormalizations
 };
 
+// Activations of the convolution block kept for the backward pass, chain-tiled like TbSave: the shortcut
+// convolution s and the pre-activations a1, a2 of the two 3-tap convolutions (model.py:130-138).
+struct ConvSave {
+    f32x4_tr *s, *a1, *a2;
+};
+// One BatchNormalization in training mode as the fused kernels see it: column sums [sum | sum of squares] of the
+// layer's input over the whole batch (complete before the kernel starts), the row count they cover, the raw
+// gamma / beta vectors, and where the first workgroup leaves the batch mean / variance for the moving statistics.
+struct BnFwd {
+    const float* stats;
+    float inv_rows;
+    const float *gamma, *beta;
+    float *batch_mean, *batch_var;
+};
+// The same layer in the backward pass: `sums` = [sum dz | sum dz*y] over the whole batch (y the layer's input;
+// sum dz*xhat follows as inv * (sum dz*y - mean * sum dz)), `own` this replica's share (the first workgroup adds
+// it to the gamma / beta gradients).
+struct BnBwd {
+    const float* stats;
+    float inv_rows;
+    const float* gamma;
+    const float* beta;
+    const float *sums, *own;
+    float *dgamma, *dbeta;
+};
+
 struct TbFwdArgs {
     const f32x4_tr* P;     // packed branch image (dptm_layout.h), built from this step's weights
-    const float* x1;       // [sites*wlen][64] input of the first block (row-major)
+    ConvSave cs;           // input of the first block: x1 = BN2(swish(a2)) + s
+    BnFwd bn2;
     TbSave sv[2];
     f32x2_tr* pool;        // per lane: {tanh score, pooling weight alpha}
     float* out;            // pooled rows: out[site*ldo + col_off + f]
@@ -166,18 +193,20 @@ hipError_t t_tb_fwd(const TbFwdArgs& a, int wlen, int NW, hipStream_t st);
 //   24 weight-gradient units of 4096 (MFMA accumulator order) | 30 vectors of 64
 constexpr int kTbUnits = 24;
 constexpr int kTbVecs = 30;
-constexpr int kTbPartStride = kTbUnits * 4096 + kTbVecs * 64 + 128;   // rounded to a multiple of 256
+constexpr int kTbPartStride = kTbUnits * 4096 + kTbVecs * 64 + 128;   // 100,352: a multiple of 256
 constexpr int kTbMaxParts = 256;
 struct TbBwdArgs {
     const f32x4_tr* P;
     const f32x4_tr* PT;    // [2][kBtSize] transposed images
-    const float* x1;
+    ConvSave cs;
+    BnFwd bn2;             // (batch_mean / batch_var unused)
+    float* bn2_sums;       // [sum d(x1) | sum d(x1) * swish(a2)] of this replica, added with atomics (zeroed per step)
     TbSave sv[2];
     const f32x2_tr* pool;
     const float* dout;     // gradient of the pooled rows: dout[site*ldd + col_off + f]
     int64_t ldd;
     int col_off;
-    float* dx1;            // [sites*wlen][64] gradient w.r.t. x1 (row-major)
+    f32x4_tr* dx1;         // gradient w.r.t. x1, chain-tiled
     float* part;           // [grid][kTbPartStride]
     int64_t n_sites;
     int S;
@@ -193,5 +222,55 @@ struct TbGrads {
     float *poolw, *poolb;
 };
 hipError_t t_tb_bwd(const TbBwdArgs& a, const TbGrads& g, int wlen, int NW, hipStream_t st);
+
+// Sum of the workgroups' partial buffers (stride kTbPartStride) into gradient tensors: weight-gradient units
+// (unit u at float u*4096 of a buffer, MFMA accumulator order; element (k, n) goes to dst[u][k*ld[u] + n]) and
+// plain vectors (len floats at float off of a buffer).  Results are ADDED to the destinations.
+struct PartUnits {
+    int n;
+    float* dst[24];
+    int ld[24];
+};
+struct PartVecs {
+    int n;
+    float* dst[32];
+    int off[32], len[32];
+};
+hipError_t t_reduce_parts(const float* part, int nparts, const PartUnits& u, const PartVecs& v, hipStream_t st);
+
+// ---- fused embedding + residual convolution block (dptm_train_conv.hip); transposed images of the convolution
+// kernels follow the two blocks' images in PT: shortcut^T, conv3a taps^T, conv3b taps^T (packed 64 x 64 each)
+constexpr int kBtConv = 2 * kBtSize;
+constexpr int kBtScT = kBtConv;
+constexpr int kBtC3aT = kBtScT + 1024;
+constexpr int kBtC3bT = kBtC3aT + 3 * 1024;
+constexpr int kBtTotal = kBtC3bT + 3 * 1024;
+
+struct ConvArgs {
+    const f32x4_tr* P;
+    const f32x4_tr* PT;
+    const uint8_t* tok;        // [sites][wlen] residue codes
+    ConvSave cs;
+    BnFwd bn1;                 // forward kernels
+    float *stats1, *stats2;    // column sums a forward kernel adds to (atomics; zeroed per step)
+    BnBwd bb1, bb2;            // backward kernels
+    float* bn1_sums;           // [sum d(z1) | sum d(z1) * swish(a1)] of this replica (atomics; zeroed per step)
+    const f32x4_tr* dx1;       // from the TransformerBlock backward kernel
+    f32x4_tr* dz1;             // gradient behind the first BatchNorm + dropout, chain-tiled (conv_b_bwd -> conv_a_bwd)
+    float* part;               // per-workgroup partial gradients, as in TbBwdArgs
+    int64_t n_sites;
+    int S;
+    int64_t ntiles;
+    const unsigned* step;
+    unsigned stream_embed, thr_embed, stream_conv, thr_conv;   // spatial dropouts: one mask value per (site, channel)
+    float scale_embed, scale_conv;
+};
+struct ConvGrads {
+    float *emb, *pos, *sck, *scb, *c3ak, *c3ab, *c3bk, *c3bb;
+};
+hipError_t t_conv_a_fwd(const ConvArgs& a, int wlen, int NW, hipStream_t st);   // tokens -> s, a1, stats1
+hipError_t t_conv_b_fwd(const ConvArgs& a, int wlen, int NW, hipStream_t st);   // a1 -> a2, stats2
+hipError_t t_conv_b_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW, hipStream_t st);   // dx1 -> dz1, conv3b / BN2 gradients
+hipError_t t_conv_a_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW, hipStream_t st);   // dz1, dx1 -> conv3a / shortcut / BN1 / embedding gradients
 
 }  // namespace dptm

@@ -1,0 +1,283 @@
+// Device and launch helpers shared by the fused training kernels (dptm_train_branch.hip: TransformerBlocks and
+// pooling; dptm_train_conv.hip: embedding and the residual convolution block): chain-layout vectors and LDS
+// images, dropout on the stateless hash, LayerNormalization, and the weight-gradient unit on the matrix cores.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dptm_layout.h"
+#include "dptm_mfma.h"
+#include "dptm_train_device.h"
+#include "dptm_train_kernels.h"
+
+namespace dptm {
+
+constexpr int kXreg = 4096;   // floats of LDS next to the two images: exchange buffer of dw_unit, small per-row arrays
+
+// ------------------------------------------------------------------------------------ device helpers
+
+template <int NT>
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+}
+
+// inverse of acc_to_x: accumulator tiles that start from a chain-layout vector
+__device__ __forceinline__ void x_to_acc(const f32x4 (&x)[8], f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][4 * g + e] = x[4 * t + g][e];
+}
+
+// chain-layout row vector <-> the lane's row of an LDS image [rows][kLdsStride]
+__device__ __forceinline__ void chain_store(float* row_base, int h, const f32x4 (&x)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x4*>(row_base + 8 * u + 4 * h) = x[u];
+}
+
+// sum over 32 image rows of column `lane` (lane = feature)
+__device__ __forceinline__ float colsum32(const float* img_rows, int lane) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; r += 2) {
+        s0 += img_rows[r * kLdsStride + lane];
+        s1 += img_rows[(r + 1) * kLdsStride + lane];
+    }
+    return s0 + s1;
+}
+
+// inverted dropout of a chain-layout row vector; the element index of (row r, feature c) is r*64 + c, as in the
+// layer-wise dropout kernels and the NumPy restatement, so every implementation sees the same mask
+__device__ __forceinline__ void dropout_chain(f32x4 (&x)[8], int64_t r, int h, unsigned seed, unsigned stream, unsigned thr,
+                                              float scale) {
+    if (thr == 0u) return;
+    const unsigned base = (unsigned)(r * 64) + 4 * h;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[u][e] = hash_u32(seed, stream, base + 8 * u + e) >= thr ? x[u][e] * scale : 0.f;
+}
+
+// acc[t] += (rows 64c .. 64c+63 of a packed [256][64] matrix)^T-product with a 64-feature chain vector: the K = 256
+// image has 32 feature groups per out tile, the chunk owns groups 8c .. 8c+7
+__device__ __forceinline__ void gemm_k256_chunk(f32x16 (&acc)[2], const f32x4* __restrict__ wp, int c, const f32x4 (&x)[8],
+                                                int lane) {
+    f32x4 a[8][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) a[u][t] = wp[(t * 32 + 8 * c + u) * 64 + lane];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        if (u + 2 < 8) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a[u + 2][t] = wp[(t * 32 + 8 * c + u + 2) * 64 + lane];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) mfma(acc[t], a[u][t][e], x[u][e]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Chain layout -> the lane's two heads: lane (h, j) gets heads 2h and 2h+1 of row j, 16 features each in natural
+// order (one exchange between the half-waves per register pair), times `scale`.
+__device__ __forceinline__ void x_to_heads(const f32x4 (&x)[8], float (&hd)[2][16], float scale) {
+    float qa[16], qb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        qa[r] = x[r >> 2][r & 3] * scale;
+        qb[r] = x[4 + (r >> 2)][r & 3] * scale;
+        half_swap(qa[r], qb[r]);
+    }
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+        const int src = 4 * (d >> 3) + (d & 3);
+        hd[0][d] = (d & 4) ? qb[src] : qa[src];
+        hd[1][d] = (d & 4) ? qb[8 + src] : qa[8 + src];
+    }
+}
+__device__ __forceinline__ void heads_to_x(const float (&hd)[2][16], f32x4 (&x)[8], float scale) {
+    float qa[16], qb[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+        const int dst = 4 * (d >> 3) + (d & 3);
+        if (d & 4) {
+            qb[dst] = hd[0][d] * scale;
+            qb[8 + dst] = hd[1][d] * scale;
+        } else {
+            qa[dst] = hd[0][d] * scale;
+            qa[8 + dst] = hd[1][d] * scale;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        half_swap(qa[r], qb[r]);
+        x[r >> 2][r & 3] = qa[r];
+        x[4 + (r >> 2)][r & 3] = qb[r];
+    }
+}
+
+// keras LayerNormalization(epsilon=1e-6): y (the summed input) becomes xhat; returns 1/sigma
+__device__ __forceinline__ float ln_normalise(f32x4 (&y)[8]) {
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (y[u][0] + y[u][1]) + (y[u][2] + y[u][3]);
+    const float mean = xhalf_sum(s) * (1.0f / 64.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = y[u][e] - mean;
+            y[u][e] = d;
+            q = fmaf(d, d, q);
+        }
+    const float inv = rsqrtf(xhalf_sum(q) * (1.0f / 64.0f) + 1e-6f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) y[u] *= inv;
+    return inv;
+}
+
+// out = xhat * gamma + beta with packed vectors (float4 index h*8 + u)
+__device__ __forceinline__ void ln_affine(const f32x4 (&xh)[8], const f32x4* __restrict__ g, const f32x4* __restrict__ b, int h,
+                                          f32x4 (&out)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) out[u] = xh[u] * g[h * 8 + u] + b[h * 8 + u];
+}
+
+// Backward of LayerNormalization for the lane's row: dy -> dsum = inv * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)).
+// The parameter gradients need column sums over rows: dy * xhat goes to the lane's row of imgA and dy to imgB (the
+// wavefront's own 32 rows of two idle images), from where colsum32 takes them.
+__device__ __forceinline__ void ln_backward(const f32x4 (&dy)[8], const f32x4 (&xh)[8], float inv, const f32x4* __restrict__ g,
+                                            int h, f32x4 (&dsum)[8], float* rowA, float* rowB) {
+    float s1 = 0.f, s2 = 0.f;
+    f32x4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        t[u] = dy[u] * xh[u];
+        dsum[u] = dy[u] * g[h * 8 + u];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s1 += dsum[u][e];
+            s2 = fmaf(dsum[u][e], xh[u][e], s2);
+        }
+    }
+    chain_store(rowA, h, t);
+    chain_store(rowB, h, dy);
+    s1 = xhalf_sum(s1) * (1.0f / 64.0f);
+    s2 = xhalf_sum(s2) * (1.0f / 64.0f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dsum[u] = inv * (dsum[u] - s1 - xh[u] * s2);
+}
+
+// One 64 x 64 weight-gradient unit: part_u (+)= X^T Y over the rows of the tile, X and Y being LDS images.  The
+// caller has put a barrier between writing the images and this call; the call ends with one barrier, after which
+// the images (not xchg) may be overwritten.  xchg: 4096 floats of LDS that nothing else uses across the call.
+// part_u: this workgroup's 4096 floats for the unit, accumulator order [block][register][lane].
+__device__ __forceinline__ void dw_unit(const float* imgX, const float* imgY, int NW, float* xchg, float* __restrict__ part_u,
+                                        bool first, int lane, int wave) {
+    const int hh = lane >> 5, i = lane & 31;
+    if (NW >= 4) {
+        // wavefront w: block w & 3 over row half w >> 2 (NW = 4: one "half" of all 128 rows)
+        const int b = wave & 3, sp = wave >> 2;
+        const float* ap = imgX + (sp * 128 + hh) * kLdsStride + 32 * (b >> 1) + i;
+        const float* bp = imgY + (sp * 128 + hh) * kLdsStride + 32 * (b & 1) + i;
+        float* dst = part_u + b * 1024 + lane;
+        f32x16 acc;
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) acc[rg] = 0.f;
+        if (sp == 0 && !first) {
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) acc[rg] = dst[rg * 64];
+        }
+#pragma unroll 8
+        for (int q = 0; q < 64; ++q) mfma(acc, ap[2 * q * kLdsStride], bp[2 * q * kLdsStride]);
+        if (sp == 1) {
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) xchg[(b * 16 + rg) * 64 + lane] = acc[rg];
+        }
+        __syncthreads();
+        if (sp == 0) {
+            if (NW == 8) {
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) acc[rg] += xchg[(b * 16 + rg) * 64 + lane];
+            }
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) dst[rg * 64] = acc[rg];
+        }
+    } else {
+        // one or two wavefronts: 4 / NW blocks each over all rows
+        const int bpw = 4 / NW, steps = NW * 16;
+        for (int bi = 0; bi < bpw; ++bi) {
+            const int b = wave * bpw + bi;
+            const float* ap = imgX + hh * kLdsStride + 32 * (b >> 1) + i;
+            const float* bp = imgY + hh * kLdsStride + 32 * (b & 1) + i;
+            float* dst = part_u + b * 1024 + lane;
+            f32x16 acc;
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) acc[rg] = first ? 0.f : dst[rg * 64];
+#pragma unroll 8
+            for (int q = 0; q < steps; ++q) mfma(acc, ap[2 * q * kLdsStride], bp[2 * q * kLdsStride]);
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) dst[rg * 64] = acc[rg];
+        }
+        __syncthreads();
+    }
+}
+
+// scale | shift of a BatchNormalization in training mode from the column sums of its input (keras epsilon 1e-3,
+// biased variance): bnv[c] = inv*gamma, bnv[64 + c] = beta - mean*inv*gamma.  Threads 0..63 of a workgroup; the
+// caller puts a barrier behind it.  `publish`: also leave the batch mean / variance for the moving statistics.
+__device__ __forceinline__ void bn_prepare(const BnFwd& bn, float* bnv, int tid, bool publish) {
+    if (tid < 64) {
+        const float mu = bn.stats[tid] * bn.inv_rows;
+        float var = bn.stats[64 + tid] * bn.inv_rows - mu * mu;
+        var = var < 0.f ? 0.f : var;
+        const float sc = rsqrtf(var + 1e-3f) * bn.gamma[tid];
+        bnv[tid] = sc;
+        bnv[64 + tid] = bn.beta[tid] - mu * sc;
+        if (publish) {
+            bn.batch_mean[tid] = mu;
+            bn.batch_var[tid] = var;
+        }
+    }
+}
+
+// input of the first TransformerBlock for the lane's row: x1 = BN2(swish(a2)) + s (model.py:138-141); zero on padding rows
+__device__ __forceinline__ void x1_from_conv(const ConvSave& cs, int64_t ct, const float* bnv, int h, bool row_ok, f32x4 (&x1)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const f32x4 a = cs.a2[ct + u * 64], sv = cs.s[ct + u * 64];
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(bnv + 8 * u + 4 * h);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(bnv + 64 + 8 * u + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x1[u][e] = row_ok ? fmaf(swishf(a[e]), sc[e], sh[e]) + sv[e] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------ launch helpers
+
+template <typename K>
+inline hipError_t lds_opt_in(K kernel, bool (&done)[64], size_t bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (done[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) done[dev] = true;
+    return e;
+}
+
+inline bool tile_ok(int wlen, int S, int NW, int64_t n, int64_t ntiles) {
+    return (wlen == 21 || wlen == 33 || wlen == 51) && (NW == 1 || NW == 2 || NW == 4 || NW == 8) && S >= 1 && S * wlen <= NW * 32 &&
+           ntiles == (n + S - 1) / S;
+}
+
+}  // namespace dptm

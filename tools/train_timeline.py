@@ -1,0 +1,18 @@
+"""Timeline of ONE training step from gpurun_out/train_trace (tools/train_trace.sh): every kernel of the last traced
+step with its start offset, duration and queue, and the idle gaps on the critical path."""
+import csv, glob, sys
+f = glob.glob("gpurun_out/train_trace/*/*kernel_trace.csv")[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# steps are separated by the AdamW kernel
+ends = [i for i, r in enumerate(rows) if "adamw" in r["Kernel_Name"]]
+lo, hi = ends[-2] + 1, ends[-1] + 1
+step = rows[lo:hi]
+t0 = int(step[0]["Start_Timestamp"])
+busy_until = t0
+print("kernels in step:", len(step), " span %.1f us" % ((int(step[-1]["End_Timestamp"]) - t0) / 1e3))
+for r in step:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    gap = (s - busy_until) / 1e3
+    busy_until = max(busy_until, e)
+    print("%8.1f us  +%6.1f us  gap %6.1f  q%-3s %s" % ((s - t0) / 1e3, (e - s) / 1e3, gap, r.get("Queue_Id", "?"), r["Kernel_Name"][:70]))
