@@ -711,9 +711,18 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
     }
     for (int b = 0; b < 3; ++b) T_TRY(hipStreamWaitEvent(st, t->ev_join[1][b], 0));
     // l2 kernel regularisers (model.py:130-138,200,204): value into the loss, 2*lambda*w into the gradient
-    if (o->l2 > 0.f)
+    if (o->l2 > 0.f) {
+        L2Segs segs;
+        segs.n = 0;
         for (const Tn& x : pm.t)
-            if (x.l2) T_TRY(t_l2(t->W + x.off, t->G + x.off, x.size, o->l2 * o->l2_scale, t->d_loss, st));
+            if (x.l2) {
+                if (segs.n == 16) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward: more than 16 regularised tensors");
+                segs.off[segs.n] = x.off;
+                segs.size[segs.n] = x.size;
+                segs.n += 1;
+            }
+        T_TRY(t_l2(t->W, t->G, segs, o->l2 * o->l2_scale, t->d_loss, st));
+    }
     return DPTM_OK;
 }
 

@@ -738,41 +738,49 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
 
 // ------------------------------------------------------------------------------------ partial sums -> gradients
 
-// grid (16, units): thread o of a unit is accumulator element [block o>>10][register (o>>6)&15][lane o&63]
-__global__ __launch_bounds__(256) void reduce_units_kernel(const float* __restrict__ part, int nparts, PartUnits tab) {
-    const int u = blockIdx.y;
-    const int o = blockIdx.x * 256 + threadIdx.x;
-    const float* src = part + (size_t)u * 4096 + o;
+// One launch sums every unit and vector of the partial buffers.  grid.x = work item: 16 per unit (256 accumulator
+// elements each: thread o of a unit is element [block o>>10][register (o>>6)&15][lane o&63]), then the vectors in
+// chunks of 256 floats; grid.y = part group: group y adds parts y, y + gridDim.y, ... and its sum joins the
+// destination through one atomic per element (the destinations start from the step's zeroed gradient buffer).
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int nparts, PartUnits ut, PartVecs vt) {
+    const int item = blockIdx.x;
+    const float* src;
+    float* dst;
+    if (item < ut.n * 16) {
+        const int u = item >> 4, o = (item & 15) * 256 + threadIdx.x;
+        const int b = o >> 10, rg = (o >> 6) & 15, lane = o & 63;
+        const int k = 32 * (b >> 1) + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5), n = 32 * (b & 1) + (lane & 31);
+        src = part + (size_t)u * 4096 + o;
+        dst = ut.dst[u] + (size_t)k * ut.ld[u] + n;
+    } else {
+        int c = item - ut.n * 16, v = 0;
+        while (v < vt.n && c >= (vt.len[v] + 255) / 256) {
+            c -= (vt.len[v] + 255) / 256;
+            ++v;
+        }
+        const int f = c * 256 + threadIdx.x;
+        if (v >= vt.n || f >= vt.len[v]) return;
+        src = part + vt.off[v] + f;
+        dst = vt.dst[v] + f;
+    }
     float a0 = 0.f, a1 = 0.f;
-    int pi = 0;
-    for (; pi + 1 < nparts; pi += 2) {
+    int pi = blockIdx.y;
+    const int stepp = gridDim.y;
+    for (; pi + stepp < nparts; pi += 2 * stepp) {
         a0 += src[(size_t)pi * kTbPartStride];
-        a1 += src[(size_t)(pi + 1) * kTbPartStride];
+        a1 += src[(size_t)(pi + stepp) * kTbPartStride];
     }
     if (pi < nparts) a0 += src[(size_t)pi * kTbPartStride];
-    const int b = o >> 10, rg = (o >> 6) & 15, lane = o & 63;
-    const int k = 32 * (b >> 1) + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5), n = 32 * (b & 1) + (lane & 31);
-    tab.dst[u][(size_t)k * tab.ld[u] + n] += a0 + a1;
-}
-
-// grid (vectors, ceil(longest / 256))
-__global__ __launch_bounds__(256) void reduce_vecs_kernel(const float* __restrict__ part, int nparts, PartVecs tab) {
-    const int v = blockIdx.x, f = blockIdx.y * 256 + threadIdx.x;
-    if (f >= tab.len[v]) return;
-    const float* src = part + tab.off[v] + f;
-    float a = 0.f;
-    for (int pi = 0; pi < nparts; ++pi) a += src[(size_t)pi * kTbPartStride];
-    tab.dst[v][f] += a;
+    atomicAdd(dst, a0 + a1);
 }
 
 hipError_t t_reduce_parts(const float* part, int nparts, const PartUnits& u, const PartVecs& v, hipStream_t st) {
-    if (u.n > 0) hipLaunchKernelGGL(reduce_units_kernel, dim3(16, (unsigned)u.n), dim3(256), 0, st, part, nparts, u);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    int longest = 0;
-    for (int i = 0; i < v.n; ++i) longest = v.len[i] > longest ? v.len[i] : longest;
-    if (v.n > 0 && longest > 0)
-        hipLaunchKernelGGL(reduce_vecs_kernel, dim3((unsigned)v.n, (unsigned)((longest + 255) / 256)), dim3(256), 0, st, part, nparts, v);
+    int items = u.n * 16;
+    for (int i = 0; i < v.n; ++i) items += (v.len[i] + 255) / 256;
+    if (items == 0 || nparts == 0) return hipSuccess;
+    int groups = (nparts + 15) / 16;
+    groups = groups > 8 ? 8 : groups;
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)items, (unsigned)groups), dim3(256), 0, st, part, nparts, u, v);
     return hipGetLastError();
 }
 

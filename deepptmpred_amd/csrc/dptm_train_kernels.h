@@ -97,7 +97,12 @@ hipError_t t_pool_bwd(const float* x, const float* w, const float* dout, int64_t
                       const float* alpha_save, float* dx, float* dw, float* db, int64_t samples, int wlen, hipStream_t st);
 hipError_t t_head_loss(const float* x, const float* W, const float* bias, const int32_t* labels, int64_t n,
                        const unsigned* step_params, float* proba, float* loss, float* dx, float* dW, float* db, hipStream_t st);
-hipError_t t_l2(const float* w, float* g, int64_t n, float lambda, float* loss, hipStream_t st);
+// l2 kernel regularisers: segments (offset, size) of the flat weight / gradient buffers, all in one launch
+struct L2Segs {
+    int n;
+    int64_t off[16], size[16];
+};
+hipError_t t_l2(const float* w, float* g, const L2Segs& segs, float lambda, float* loss, hipStream_t st);
 hipError_t t_adamw(float* w, const float* g, float* m, float* v, const uint8_t* trainable, float stat_scale, int64_t n,
                    float lr_t, float wd, float b1, float b2, float eps, float gscale, hipStream_t st);
 

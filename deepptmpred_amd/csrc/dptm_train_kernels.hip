@@ -974,79 +974,114 @@ __global__ __launch_bounds__(64) void pool_bwd_kernel(const float* __restrict__ 
 
 // ------------------------------------------------------------------------------------ head + loss
 
-// Per sample: logits = x.W + b (W [256][2]), softmax, class-balanced BCE (trainer.py:36-54),
-// d(logits); then dW, db (atomics) and dx.  One wavefront per sample.
-__global__ __launch_bounds__(64) void head_loss_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                                       const float* __restrict__ bias, const int32_t* __restrict__ labels,
-                                                       int64_t n, const unsigned* __restrict__ step_params,
-                                                       float* __restrict__ proba, float* __restrict__ loss,
-                                                       float* __restrict__ dx, float* __restrict__ dW,
-                                                       float* __restrict__ db) {
+// Per sample: logits = x.W + b (W [256][2]), softmax, class-balanced BCE (trainer.py:36-54), d(logits), d(x).
+// A wavefront walks samples wave, wave + nwaves, ...; the gradients of W and b are summed in registers over the
+// wavefront's samples, then over the workgroup in LDS, and leave through one set of atomics per workgroup.
+__global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, const int32_t* __restrict__ labels,
+                                                        int64_t n, const unsigned* __restrict__ step_params,
+                                                        float* __restrict__ proba, float* __restrict__ loss,
+                                                        float* __restrict__ dx, float* __restrict__ dW,
+                                                        float* __restrict__ db) {
+    __shared__ float red[4][8][64];
+    __shared__ float red_s[4][4];
     const float n_global = __uint_as_float(step_params[kStepNGlobal]);
     const float n_pos_global = __uint_as_float(step_params[kStepNPosGlobal]);
-    const int64_t s = blockIdx.x;
-    const int lane = threadIdx.x;
-    float l0 = 0.f, l1 = 0.f;
-    float xv[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float w0[4], w1[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        xv[i] = x[s * 256 + lane + 64 * i];
-        l0 = fmaf(xv[i], W[(lane + 64 * i) * 2], l0);
-        l1 = fmaf(xv[i], W[(lane + 64 * i) * 2 + 1], l1);
+        w0[i] = W[(lane + 64 * i) * 2];
+        w1[i] = W[(lane + 64 * i) * 2 + 1];
+    }
+    const float b0 = bias[0], b1 = bias[1];
+    float g0[4] = {0.f, 0.f, 0.f, 0.f}, g1[4] = {0.f, 0.f, 0.f, 0.f};
+    float sl = 0.f, sd0 = 0.f, sd1 = 0.f;
+    for (int64_t s = (int64_t)blockIdx.x * 4 + wave; s < n; s += (int64_t)gridDim.x * 4) {
+        float l0 = 0.f, l1 = 0.f;
+        float xv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xv[i] = x[s * 256 + lane + 64 * i];
+            l0 = fmaf(xv[i], w0[i], l0);
+            l1 = fmaf(xv[i], w1[i], l1);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            l0 += __shfl_xor(l0, o);
+            l1 += __shfl_xor(l1, o);
+        }
+        l0 += b0;
+        l1 += b1;
+        const float m = fmaxf(l0, l1);
+        const float e0 = __expf(l0 - m), e1 = __expf(l1 - m);
+        const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+        const float eps = 1e-7f;
+        const int y = labels[s];
+        const float wt = y ? n_global / (2.0f * n_pos_global + eps) : n_global / (2.0f * (n_global - n_pos_global) + eps);
+        // keras binary_crossentropy over both softmax columns with the one-hot target.  For a
+        // 2-class softmax 1-p0 = p1, so the four log terms collapse to -2*log(c_y + eps) with
+        // c_y the clipped probability of the true class; this form is algebraically the same
+        // as the literal one and avoids its 1-p cancellation in fp32.
+        const float py = y ? p1 : p0;
+        const float cy = fminf(fmaxf(py, eps), 1.0f - eps);
+        const float bce = -2.0f * logf(cy + eps);
+        const float scale = wt / (n_global * 2.0f);
+        // d(scale*bce)/d(logit_i) = 2*scale * py/(cy+eps) * (p_i - [i == y]); zero where the clip is active
+        const float gy = (py > eps && py < 1.0f - eps) ? 2.0f * scale * py / (cy + eps) : 0.f;
+        const float d0 = gy * (p0 - (y ? 0.f : 1.f)), d1 = gy * (p1 - (y ? 1.f : 0.f));
+        if (lane == 0) {
+            proba[s * 2] = p0;
+            proba[s * 2 + 1] = p1;
+        }
+        sl += scale * bce;
+        sd0 += d0;
+        sd1 += d1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dx[s * 256 + lane + 64 * i] = d0 * w0[i] + d1 * w1[i];
+            g0[i] = fmaf(d0, xv[i], g0[i]);
+            g1[i] = fmaf(d1, xv[i], g1[i]);
+        }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        l0 += __shfl_xor(l0, o);
-        l1 += __shfl_xor(l1, o);
+    for (int i = 0; i < 4; ++i) {
+        red[wave][i][lane] = g0[i];
+        red[wave][4 + i][lane] = g1[i];
     }
-    l0 += bias[0];
-    l1 += bias[1];
-    const float m = fmaxf(l0, l1);
-    const float e0 = __expf(l0 - m), e1 = __expf(l1 - m);
-    const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
-    const float eps = 1e-7f;
-    const int y = labels[s];
-    const float wt = y ? n_global / (2.0f * n_pos_global + eps) : n_global / (2.0f * (n_global - n_pos_global) + eps);
-    // keras binary_crossentropy over both softmax columns with the one-hot target.  For a
-    // 2-class softmax 1-p0 = p1, so the four log terms collapse to -2*log(c_y + eps) with
-    // c_y the clipped probability of the true class; this form is algebraically the same
-    // as the literal one and avoids its 1-p cancellation in fp32.
-    const float py = y ? p1 : p0;
-    const float cy = fminf(fmaxf(py, eps), 1.0f - eps);
-    const float bce = -2.0f * logf(cy + eps);
-    const float scale = wt / (n_global * 2.0f);
-    // d(scale*bce)/d(logit_i) = 2*scale * py/(cy+eps) * (p_i - [i == y]); zero where the clip is active
-    const float gy = (py > eps && py < 1.0f - eps) ? 2.0f * scale * py / (cy + eps) : 0.f;
-    const float d0 = gy * (p0 - (y ? 0.f : 1.f)), d1 = gy * (p1 - (y ? 1.f : 0.f));
     if (lane == 0) {
-        proba[s * 2] = p0;
-        proba[s * 2 + 1] = p1;
-        atomicAdd(loss, scale * bce);
-        atomicAdd(db, d0);
-        atomicAdd(db + 1, d1);
+        red_s[wave][0] = sl;
+        red_s[wave][1] = sd0;
+        red_s[wave][2] = sd1;
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = lane + 64 * i;
-        dx[s * 256 + f] = d0 * W[f * 2] + d1 * W[f * 2 + 1];
-        atomicAdd(dW + f * 2, d0 * xv[i]);
-        atomicAdd(dW + f * 2 + 1, d1 * xv[i]);
+    __syncthreads();
+    for (int o = threadIdx.x; o < 512; o += 256) {
+        const int c = o >> 8, f = o & 255;          // class, feature
+        const float v = red[0][4 * c + (f >> 6)][f & 63] + red[1][4 * c + (f >> 6)][f & 63] + red[2][4 * c + (f >> 6)][f & 63] +
+                        red[3][4 * c + (f >> 6)][f & 63];
+        if (v != 0.f) atomicAdd(dW + f * 2 + c, v);
+    }
+    if (threadIdx.x < 3) {
+        const float v = red_s[0][threadIdx.x] + red_s[1][threadIdx.x] + red_s[2][threadIdx.x] + red_s[3][threadIdx.x];
+        atomicAdd(threadIdx.x == 0 ? loss : db + threadIdx.x - 1, v);
     }
 }
 
 // ------------------------------------------------------------------------------------ optimiser
 
-// sum of squares of a tensor (for the l2 regulariser value) and g += 2*lambda*w
-__global__ void l2_kernel(const float* __restrict__ w, float* __restrict__ g, int64_t n, float lambda, float* __restrict__ loss) {
+// l2 kernel regularisers of all regularised tensors in one launch (grid.y = tensor): lambda * sum w^2 into the loss
+// and g += 2*lambda*w.  Segments are offsets into the flat weight / gradient buffers.
+__global__ void l2_kernel(const float* __restrict__ w, float* __restrict__ g, L2Segs segs, float lambda, float* __restrict__ loss) {
+    const int64_t off = segs.off[blockIdx.y], n = segs.size[blockIdx.y];
     float s = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = w[i];
-        g[i] += 2.0f * lambda * v;
+        const float v = w[off + i];
+        g[off + i] += 2.0f * lambda * v;
         s = fmaf(v, v, s);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0) atomicAdd(loss, lambda * s);
+    if ((threadIdx.x & 63) == 0 && s != 0.f) atomicAdd(loss, lambda * s);
 }
 
 // tensorflow-addons AdamW: w -= wd*w, then keras Adam with lr_t = lr*sqrt(1-b2^t)/(1-b1^t).
@@ -1287,7 +1322,10 @@ hipError_t t_pool_bwd(const float* x, const float* w, const float* dout, int64_t
 }
 hipError_t t_head_loss(const float* x, const float* W, const float* bias, const int32_t* labels, int64_t n,
                        const unsigned* step_params, float* proba, float* loss, float* dx, float* dW, float* db, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(head_loss_kernel, dim3((unsigned)n), dim3(64), 0, st, x, W, bias, labels, n, step_params, proba, loss, dx, dW, db);
+    if (n) {
+        const int64_t blocks = (n + 3) / 4 < 256 ? (n + 3) / 4 : 256;
+        hipLaunchKernelGGL(head_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, W, bias, labels, n, step_params, proba, loss, dx, dW, db);
+    }
     return hipGetLastError();
 }
 __global__ void set_step_kernel(unsigned* step_params, unsigned seed, float n_global, float n_pos_global) {
@@ -1301,8 +1339,8 @@ hipError_t t_set_step(unsigned* step_params, unsigned seed, float n_global, floa
     hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(64), 0, st, step_params, seed, n_global, n_pos_global);
     return hipGetLastError();
 }
-hipError_t t_l2(const float* w, float* g, int64_t n, float lambda, float* loss, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(l2_kernel, dim3(grid_for(n, 256, 64)), dim3(256), 0, st, w, g, n, lambda, loss);
+hipError_t t_l2(const float* w, float* g, const L2Segs& segs, float lambda, float* loss, hipStream_t st) {
+    if (segs.n > 0) hipLaunchKernelGGL(l2_kernel, dim3(64, (unsigned)segs.n), dim3(256), 0, st, w, g, segs, lambda, loss);
     return hipGetLastError();
 }
 hipError_t t_adamw(float* w, const float* g, float* m, float* v, const uint8_t* trainable, float stat_scale, int64_t n,
