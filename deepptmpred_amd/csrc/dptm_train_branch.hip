@@ -383,9 +383,10 @@ template <int W>
 __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int NW = blockDim.x >> 6, rows_tile = NW * 32;
+    const int img = img_floats(NW);                  // room for a row-major [rows][68] or a transposed [64][rows + 4] image
     float* bufA = lds;
-    float* bufB = bufA + rows_tile * kLdsStride;
-    float* xreg = bufB + rows_tile * kLdsStride;
+    float* bufB = bufA + img;
+    float* xreg = bufB + img;
     float* vacc = xreg + kXreg;                     // [kTbVecs][64] column sums of this workgroup
     float* bnv = vacc + kTbVecs * 64;               // [scale | shift] of the second BatchNorm
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -398,6 +399,9 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
     float* mine_a = own_a + j * kLdsStride;
     float* mine_b = own_b + j * kLdsStride;
     const int att_start = min(row / W, S - 1) * W;
+    const int row0 = wave * 32;
+    float* lane_a = bufA + 4 * h * kTs + row;       // the lane's place in a transposed image (chain_store_t)
+    float* lane_b = bufB + 4 * h * kTs + row;
     float* part = p.part + (size_t)blockIdx.x * kTbPartStride;
     for (int i = tid; i < kTbVecs * 64; i += blockDim.x) vacc[i] = 0.f;
     bn_prepare(p.bn2, bnv, tid, false);
@@ -448,9 +452,9 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                 dy[u] = al * ds[u] + dz * pv[h * 8 + u];
                 t[u] = dz * x[u];
             }
-            chain_store(mine_a, h, t);
+            chain_store_t(lane_a, t);
             wave_fence();
-            atomicAdd(&vacc[kSPoolW * 64 + lane], colsum32(own_a, lane));
+            atomicAdd(&vacc[kSPoolW * 64 + lane], colsum32_t(bufA, row0, lane));
             float dzs = h == 0 ? dz : 0.f;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) dzs += __shfl_xor(dzs, o);
@@ -474,10 +478,10 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                 f32x4 xh[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) xh[u] = sv.xh2[ct + u * 64];
-                ln_backward(dy, xh, iv[1], tv + kVLn2G * kVec64, h, dsum, mine_a, mine_b);
+                ln_backward(dy, xh, iv[1], tv + kVLn2G * kVec64, h, dsum, lane_a, lane_b);
                 wave_fence();
-                atomicAdd(va + kSG2 * 64, colsum32(own_a, lane));
-                atomicAdd(va + kSB2 * 64, colsum32(own_b, lane));
+                atomicAdd(va + kSG2 * 64, colsum32_t(bufA, row0, lane));
+                atomicAdd(va + kSB2 * 64, colsum32_t(bufB, row0, lane));
                 wave_fence();
             }
             PH_MARK(1)   // LayerNorm 2 backward
@@ -497,35 +501,27 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
             x_to_acc(dsum, acc_dh);
 #pragma unroll 1
             for (int c = 0; c < 4; ++c) {
-                f32x4 g[8];
-                {
-                    f32x16 acc_f[2];
-                    acc_init_bias<2>(acc_f, tv + 9 * kVec64 + 8 * c, h, 32);
-                    gemm_regs<8, 2, 2>(acc_f, T + kTbF1 + (2 * c) * 8 * 64, hx, lane);     // f1_c = h W1[:, chunk] + b1
-                    f32x4 u_[8];
-                    acc_to_x<2>(acc_f, u_);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float a = u_[u][e];
-                            const float sg = fast_rcp(1.0f + __expf(-a));
-                            u_[u][e] = a * sg;                                   // swish(f1_c)
-                            g[u][e] = sg * (1.0f + a * (1.0f - sg));             // swish'(f1_c)
-                        }
-                    chain_store(mine_a, h, u_);
-                }
-                PH_MARK(2)   // feed-forward row products
-                chain_store(mine_b, h, df2);
-                if (c == 0) {
-                    wave_fence();
-                    atomicAdd(va + kSFb2 * 64, colsum32(own_b, lane));
-                }
-                __syncthreads();
-                dw_unit(bufA, bufB, NW, xreg, pu + (4 + c) * 4096, first, lane, wave);     // dW2[chunk, :] += u_c^T d(f2)
-                PH_MARK(3)   // feed-forward weight gradients
+                // all row products of the chunk first, so that little stays in registers across the weight-gradient units
                 f32x4 d1[8];
                 {
+                    f32x4 g[8];
+                    {
+                        f32x16 acc_f[2];
+                        acc_init_bias<2>(acc_f, tv + 9 * kVec64 + 8 * c, h, 32);
+                        gemm_regs<8, 2, 2>(acc_f, T + kTbF1 + (2 * c) * 8 * 64, hx, lane);     // f1_c = h W1[:, chunk] + b1
+                        f32x4 u_[8];
+                        acc_to_x<2>(acc_f, u_);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float a = u_[u][e];
+                                const float sg = fast_rcp(1.0f + __expf(-a));
+                                u_[u][e] = a * sg;                                   // swish(f1_c)
+                                g[u][e] = sg * (1.0f + a * (1.0f - sg));             // swish'(f1_c)
+                            }
+                        chain_store_t(lane_a, u_);
+                    }
                     f32x16 acc_u[2];
                     acc_zero<2>(acc_u);
                     gemm_regs<8, 2, 2>(acc_u, TT + kBtW2T + (2 * c) * 8 * 64, df2, lane);   // d(u_c) = d(f2) W2[chunk, :]^T
@@ -533,15 +529,24 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) d1[u] *= g[u];                             // d(f1_c)
                 }
-                PH_MARK(2)
-                chain_store(mine_a, h, hx);
-                chain_store(mine_b, h, d1);
-                wave_fence();
-                atomicAdd(va + (kSFb1 + c) * 64, colsum32(own_b, lane));
+                chain_store_t(lane_b, df2);
+                if (c == 0) {
+                    wave_fence();
+                    atomicAdd(va + kSFb2 * 64, colsum32_t(bufB, row0, lane));
+                }
+                PH_MARK(2)   // feed-forward row products
                 __syncthreads();
-                dw_unit(bufA, bufB, NW, xreg, pu + c * 4096, first, lane, wave);           // dW1[:, chunk] += h^T d(f1_c)
-                PH_MARK(3)
+                dw_unit_t(bufA, bufB, NW, xreg, pu + (4 + c) * 4096, first, lane, wave);     // dW2[chunk, :] += u_c^T d(f2)
+                PH_MARK(3)   // feed-forward weight gradients
+                chain_store_t(lane_a, hx);
+                chain_store_t(lane_b, d1);
+                wave_fence();
+                atomicAdd(va + (kSFb1 + c) * 64, colsum32_t(bufB, row0, lane));
                 gemm_k256_chunk(acc_dh, TT + kBtW1T, c, d1, lane);                         // d(h) += d(f1_c) W1[:, chunk]^T
+                PH_MARK(2)
+                __syncthreads();
+                dw_unit_t(bufA, bufB, NW, xreg, pu + c * 4096, first, lane, wave);           // dW1[:, chunk] += h^T d(f1_c)
+                PH_MARK(3)
             }
             PH_MARK(2)
             // ---- LayerNorm 1 backward: d(h) -> dsum = d(x + ao)
@@ -550,10 +555,10 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                 acc_to_x<2>(acc_dh, dh);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) xh[u] = sv.xh1[ct + u * 64];
-                ln_backward(dh, xh, iv[0], tv + kVLn1G * kVec64, h, dsum, mine_a, mine_b);
+                ln_backward(dh, xh, iv[0], tv + kVLn1G * kVec64, h, dsum, lane_a, lane_b);
                 wave_fence();
-                atomicAdd(va + kSG1 * 64, colsum32(own_a, lane));
-                atomicAdd(va + kSB1 * 64, colsum32(own_b, lane));
+                atomicAdd(va + kSG1 * 64, colsum32_t(bufA, row0, lane));
+                atomicAdd(va + kSB1 * 64, colsum32_t(bufB, row0, lane));
                 wave_fence();
             }
             PH_MARK(4)   // LayerNorm 1 backward
@@ -568,12 +573,12 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                     o[u] = sv.o[ct + u * 64];
                 }
                 dropout_chain(dao, grow, h, seed, p.stream_base + 2 * blk, p.thr, p.scale);
-                chain_store(mine_a, h, o);
-                chain_store(mine_b, h, dao);
+                chain_store_t(lane_a, o);
+                chain_store_t(lane_b, dao);
                 wave_fence();
-                atomicAdd(va + kSBo * 64, colsum32(own_b, lane));
+                atomicAdd(va + kSBo * 64, colsum32_t(bufB, row0, lane));
                 __syncthreads();
-                dw_unit(bufA, bufB, NW, xreg, pu + 8 * 4096, first, lane, wave);           // dWo += o^T d(ao)
+                dw_unit_t(bufA, bufB, NW, xreg, pu + 8 * 4096, first, lane, wave);           // dWo += o^T d(ao)
                 f32x16 acc[2];
                 acc_zero<2>(acc);
                 gemm_regs<8, 2>(acc, TT + kBtWoT, dao, lane);                              // d(o) = d(ao) Wo^T
@@ -630,13 +635,13 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                         for (int u = 0; u < 8; ++u) xin[u] = p.sv[0].xh2[ct + u * 64];
                         ln_affine(xin, tv0 + kVLn2G * kVec64, tv0 + kVLn2B * kVec64, h, xin);
                     }
-                    chain_store(mine_a, h, xin);
+                    chain_store_t(lane_a, xin);
                 }
-                chain_store(mine_b, h, dq);
+                chain_store_t(lane_b, dq);
                 wave_fence();
-                atomicAdd(va + kSBq * 64, colsum32(own_b, lane));
+                atomicAdd(va + kSBq * 64, colsum32_t(bufB, row0, lane));
                 __syncthreads();
-                dw_unit(bufA, bufB, NW, xreg, pu + 9 * 4096, first, lane, wave);           // dWq += x^T dq
+                dw_unit_t(bufA, bufB, NW, xreg, pu + 9 * 4096, first, lane, wave);           // dWq += x^T dq
                 x_to_acc(dsum, acc_dx);
                 gemm_regs<8, 2>(acc_dx, TT + kBtWqT, dq, lane);
             }
@@ -686,19 +691,19 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                         for (int u = 0; u < 8; ++u) xin[u] = p.sv[0].xh2[ct + u * 64];
                         ln_affine(xin, tv0 + kVLn2G * kVec64, tv0 + kVLn2B * kVec64, h, xin);
                     }
-                    chain_store(mine_a, h, xin);
+                    chain_store_t(lane_a, xin);
                 }
-                chain_store(mine_b, h, dk);
+                chain_store_t(lane_b, dk);
                 wave_fence();
-                atomicAdd(va + kSBk * 64, colsum32(own_b, lane));
+                atomicAdd(va + kSBk * 64, colsum32_t(bufB, row0, lane));
                 __syncthreads();
-                dw_unit(bufA, bufB, NW, xreg, pu + 10 * 4096, first, lane, wave);          // dWk += x^T dk
+                dw_unit_t(bufA, bufB, NW, xreg, pu + 10 * 4096, first, lane, wave);          // dWk += x^T dk
                 gemm_regs<8, 2>(acc_dx, TT + kBtWkT, dk, lane);
-                chain_store(mine_b, h, dv);
+                chain_store_t(lane_b, dv);
                 wave_fence();
-                atomicAdd(va + kSBv * 64, colsum32(own_b, lane));
+                atomicAdd(va + kSBv * 64, colsum32_t(bufB, row0, lane));
                 __syncthreads();
-                dw_unit(bufA, bufB, NW, xreg, pu + 11 * 4096, first, lane, wave);          // dWv += x^T dv
+                dw_unit_t(bufA, bufB, NW, xreg, pu + 11 * 4096, first, lane, wave);          // dWv += x^T dv
                 gemm_regs<8, 2>(acc_dx, TT + kBtWvT, dv, lane);
             }
             acc_to_x<2>(acc_dx, dy);
@@ -714,11 +719,11 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) t[u][e] = dy[u][e] * swishf(a[e]);
             }
-            chain_store(mine_a, h, dy);
-            chain_store(mine_b, h, t);
+            chain_store_t(lane_a, dy);
+            chain_store_t(lane_b, t);
             wave_fence();
-            atomicAdd(&vacc[kSBn2A * 64 + lane], colsum32(own_a, lane));
-            atomicAdd(&vacc[kSBn2B * 64 + lane], colsum32(own_b, lane));
+            atomicAdd(&vacc[kSBn2A * 64 + lane], colsum32_t(bufA, row0, lane));
+            atomicAdd(&vacc[kSBn2B * 64 + lane], colsum32_t(bufB, row0, lane));
             wave_fence();
         }
         first = false;
@@ -787,7 +792,7 @@ hipError_t t_reduce_parts(const float* part, int nparts, const PartUnits& u, con
 // ------------------------------------------------------------------------------------ launchers
 
 static size_t fwd_lds(int NW) { return ((size_t)2 * NW * 32 * kLdsStride + 2 * NW * 32 + 128) * sizeof(float); }
-static size_t bwd_lds(int NW) { return ((size_t)2 * NW * 32 * kLdsStride + kXreg + kTbVecs * 64 + 128) * sizeof(float); }
+static size_t bwd_lds(int NW) { return ((size_t)2 * img_floats(NW) + kXreg + kTbVecs * 64 + 128) * sizeof(float); }
 
 template <int W>
 static hipError_t launch_fwd(const TbFwdArgs& a, int NW, hipStream_t st) {

@@ -13,6 +13,14 @@ namespace dptm {
 
 constexpr int kXreg = 4096;   // floats of LDS next to the two images: exchange buffer of dw_unit, small per-row arrays
 
+// Transposed images [feature][row] have ONE row stride for every tile size, so that a lane's 32 stores differ by
+// compile-time offsets (a stride that depends on the tile size costs an address register per store).
+constexpr int kTs = 260;      // 256 rows + 4: 16-byte reads by 16 lanes of consecutive features hit distinct banks
+// floats of one LDS image of a tile of NW wavefronts: row-major [32 NW][68] or transposed [64][kTs]
+__host__ __device__ constexpr int img_floats(int NW) {
+    return 32 * NW * kLdsStride > 64 * kTs ? 32 * NW * kLdsStride : 64 * kTs;
+}
+
 // ------------------------------------------------------------------------------------ device helpers
 
 template <int NT>
@@ -151,11 +159,31 @@ __device__ __forceinline__ void ln_affine(const f32x4 (&xh)[8], const f32x4* __r
     for (int u = 0; u < 8; ++u) out[u] = xh[u] * g[h * 8 + u] + b[h * 8 + u];
 }
 
+// ---- transposed LDS images [feature][row] (row stride kTs): the layout the weight-gradient unit reads with
+// 16-byte loads.  A lane stores its 32 features as single floats (consecutive lanes = consecutive rows =
+// consecutive addresses).  lane_base = image + 4*h*kTs + row of the lane.
+__device__ __forceinline__ void chain_store_t(float* lane_base, const f32x4 (&x)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lane_base[(8 * u + e) * kTs] = x[u][e];
+}
+
+// sum over rows row0 .. row0+31 (row0 a multiple of 32) of feature `lane` of a transposed image
+__device__ __forceinline__ float colsum32_t(const float* imgT, int row0, int lane) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(imgT + lane * kTs + row0);
+    f32x4 s = p[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) s += p[i];
+    return (s[0] + s[1]) + (s[2] + s[3]);
+}
+
 // Backward of LayerNormalization for the lane's row: dy -> dsum = inv * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)).
-// The parameter gradients need column sums over rows: dy * xhat goes to the lane's row of imgA and dy to imgB (the
-// wavefront's own 32 rows of two idle images), from where colsum32 takes them.
+// The parameter gradients need column sums over rows: dy * xhat goes to the lane's row of one transposed image
+// (lane_a, see chain_store_t) and dy to a second one (the wavefront's own 32 rows of two idle images), from where
+// colsum32_t takes them.
 __device__ __forceinline__ void ln_backward(const f32x4 (&dy)[8], const f32x4 (&xh)[8], float inv, const f32x4* __restrict__ g,
-                                            int h, f32x4 (&dsum)[8], float* rowA, float* rowB) {
+                                            int h, f32x4 (&dsum)[8], float* lane_a, float* lane_b) {
     float s1 = 0.f, s2 = 0.f;
     f32x4 t[8];
 #pragma unroll
@@ -168,8 +196,8 @@ __device__ __forceinline__ void ln_backward(const f32x4 (&dy)[8], const f32x4 (&
             s2 = fmaf(dsum[u][e], xh[u][e], s2);
         }
     }
-    chain_store(rowA, h, t);
-    chain_store(rowB, h, dy);
+    chain_store_t(lane_a, t);
+    chain_store_t(lane_b, dy);
     s1 = xhalf_sum(s1) * (1.0f / 64.0f);
     s2 = xhalf_sum(s2) * (1.0f / 64.0f);
 #pragma unroll
@@ -229,6 +257,61 @@ __device__ __forceinline__ void dw_unit(const float* imgX, const float* imgY, in
         }
         __syncthreads();
     }
+}
+
+// dw_unit on transposed images: one 16-byte read per operand feeds four MFMA steps.  Step s of group Q contracts
+// rows 8Q + s (lower half-wave) and 8Q + 4 + s (upper half-wave); every row of the tile is met once.
+__device__ __forceinline__ void dw_unit_t(const float* imgXT, const float* imgYT, int NW, float* xchg,
+                                          float* __restrict__ part_u, bool first, int lane, int wave) {
+    const int hh = lane >> 5, i = lane & 31;
+    const int nblk = NW >= 4 ? 1 : 4 / NW;                 // blocks per wavefront
+    const int sp = NW >= 4 ? wave >> 2 : 0;                // row half (NW = 8)
+    const int nq = NW >= 4 ? 16 : NW * 4;                  // groups of 8 rows this wavefront contracts over
+    for (int bi = 0; bi < nblk; ++bi) {
+        const int b = NW >= 4 ? (wave & 3) : wave * nblk + bi;
+        const float* ap = imgXT + (32 * (b >> 1) + i) * kTs + sp * 128 + 4 * hh;
+        const float* bp = imgYT + (32 * (b & 1) + i) * kTs + sp * 128 + 4 * hh;
+        float* dst = part_u + b * 1024 + lane;
+        // the running sum of the partial buffer is requested now and added after the products, so that its
+        // latency hides behind them
+        f32x16 acc, prev;
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) acc[rg] = prev[rg] = 0.f;
+        if (sp == 0 && !first) {
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) prev[rg] = dst[rg * 64];
+        }
+        // operands one group ahead of the four products that use them
+        f32x4 ca = *reinterpret_cast<const f32x4*>(ap), cb = *reinterpret_cast<const f32x4*>(bp);
+#pragma unroll 2
+        for (int g = 0; g < nq; ++g) {
+            f32x4 na = ca, nb = cb;
+            if (g + 1 < nq) {
+                na = *reinterpret_cast<const f32x4*>(ap + 8 * (g + 1));
+                nb = *reinterpret_cast<const f32x4*>(bp + 8 * (g + 1));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mfma(acc, ca[e], cb[e]);
+            ca = na;
+            cb = nb;
+        }
+        if (NW == 8) {
+            if (sp == 1) {
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) xchg[(b * 16 + rg) * 64 + lane] = acc[rg];
+            }
+            __syncthreads();
+            if (sp == 0) {
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) acc[rg] += xchg[(b * 16 + rg) * 64 + lane];
+            }
+        }
+        if (sp == 0) {
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) dst[rg * 64] = acc[rg] + prev[rg];
+        }
+    }
+    if (NW != 8) __syncthreads();
 }
 
 // scale | shift of a BatchNormalization in training mode from the column sums of its input (keras epsilon 1e-3,
