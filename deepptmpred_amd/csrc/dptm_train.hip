@@ -139,6 +139,7 @@ struct dptm_trainer {
     Scratch sc[4];                        // [0..2] sequence branches, [3] per-site layers (BatchNorm sums only)
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    hipEvent_t ev_caller[2] = {nullptr, nullptr};   // the caller's stream hands over to / takes over from the step's streams
     float *dconcat, *d512a, *d512b, *d256a, *d256b, *d128;
     int64_t step = 0;
     int64_t last_n = 0;
@@ -478,6 +479,7 @@ void dptm_trainer_destroy(dptm_trainer* t) {
     for (int b = 0; b < 3; ++b)
         if (t->aux[b]) (void)hipStreamDestroy(t->aux[b]);
     for (int ph = 0; ph < 2; ++ph) {
+        if (t->ev_caller[ph]) (void)hipEventDestroy(t->ev_caller[ph]);
         if (t->ev_fork[ph]) (void)hipEventDestroy(t->ev_fork[ph]);
         for (int b = 0; b < 3; ++b)
             if (t->ev_join[ph][b]) (void)hipEventDestroy(t->ev_join[ph][b]);
@@ -511,7 +513,9 @@ int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spe
     for (int b = 0; b < 3; ++b)
         if (hipStreamCreateWithFlags(&t->aux[b], hipStreamNonBlocking) != hipSuccess) return bail(DPTM_EHIP, "hipStreamCreate failed");
     for (int ph = 0; ph < 2; ++ph) {
-        if (hipEventCreateWithFlags(&t->ev_fork[ph], hipEventDisableTiming) != hipSuccess) return bail(DPTM_EHIP, "hipEventCreate failed");
+        if (hipEventCreateWithFlags(&t->ev_fork[ph], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&t->ev_caller[ph], hipEventDisableTiming) != hipSuccess)
+            return bail(DPTM_EHIP, "hipEventCreate failed");
         for (int b = 0; b < 3; ++b)
             if (hipEventCreateWithFlags(&t->ev_join[ph][b], hipEventDisableTiming) != hipSuccess) return bail(DPTM_EHIP, "hipEventCreate failed");
     }
@@ -627,7 +631,15 @@ int dptm_trainer_grad_buffer(dptm_trainer* t, float** dev_ptr, int64_t* count) t
 // allocation: the sequence can be captured into a graph.  Per-step scalars come from t->d_step.
 static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
                                     const float* strct, const float* esm, const int32_t* labels, int64_t n,
-                                    const dptm_train_opts* o, hipStream_t st) {
+                                    const dptm_train_opts* o, hipStream_t caller) {
+    // The step runs on three streams of the trainer's own (created back to back, so that they land on different
+    // hardware queues: a caller's stream may share its queue with one of them, and two streams on one queue
+    // serialise); the caller's stream only waits for the step's last kernel.
+    hipStream_t st = t->serial ? caller : t->stream;
+    if (st != caller) {
+        T_TRY(hipEventRecord(t->ev_caller[0], caller));
+        T_TRY(hipStreamWaitEvent(st, t->ev_caller[0], 0));
+    }
     Ctx c{t, st, t->W, t->G, &t->sc[3]};
     const PMap& pm = t->pm;
     const Rates rt{o->rate_embed, o->rate_conv, o->rate_tb, o->rate_dense};
@@ -639,77 +651,163 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
     T_TRY(t_pack(t->pack_jobs, t->n_pack_jobs, st));          // weight images of this step's weights
     T_TRY(hipMemsetAsync(t->d_loss, 0, 64 * sizeof(float), st));
     T_TRY(hipMemsetAsync(t->bn_slots, 0, (size_t)2 * kBnLayers * 1024 * sizeof(float), st));
-    // ---------------- forward: the three sequence branches on side streams, the per-site layers on `st`
-    T_TRY(hipEventRecord(t->ev_fork[0], st));
-    for (int b = 0; b < 3; ++b) {
-        hipStream_t bs = t->serial ? st : t->aux[b];
-        T_TRY(hipStreamWaitEvent(bs, t->ev_fork[0], 0));
-        Ctx cb{t, bs, t->W, t->G, &t->sc[b]};
-        if ((rc = branch_fwd(cb, b, tok[b], B, seed, rt))) return rc;
-        T_TRY(hipEventRecord(t->ev_join[0][b], bs));
-    }
-    // struct branch (model.py:187-189)
-    auto dense_swish = [&](GemmArgs g, float* act, int64_t lda) {     // pre-activation to g.out, swish of it to act
-        g.act_out = act; g.lda = lda;
-        return t_gemm(g, false, st);
+    // Small batches without a statistics all-reduce take the per-column kernels of dptm_train_site.hip: one launch per
+    // layer and direction instead of a product and half a dozen element-wise passes each.
+    const bool small = B <= kSiteMaxRows && !t->ar_fn &&
+                       ((reinterpret_cast<uintptr_t>(strct) | reinterpret_cast<uintptr_t>(esm)) & 15) == 0;
+    // ---------------- forward.  Three lanes of work: the W=21 and W=33 branches on side streams, the W=51 branch (the
+    // longest) on the caller's stream `st`; the structure / ESM layers of a small batch follow the W=21 branch on its
+    // stream `ss`.  (The hardware has few queues: more streams than this end up sharing one and serialise.)
+    hipStream_t bstream[3] = {t->serial ? st : t->aux[0], t->serial ? st : t->aux[1], st};
+    hipStream_t ss = small ? bstream[0] : st;
+    auto branches = [&](bool forward, int first, int last) -> int {
+        for (int b = first; b <= last; ++b) {
+            Ctx cb{t, bstream[b], t->W, t->G, &t->sc[b]};
+            const int r = forward ? branch_fwd(cb, b, tok[b], B, seed, rt) : branch_bwd(cb, b, tok[b], B, seed, rt);
+            if (r) return r;
+        }
+        return DPTM_OK;
     };
-    T_TRY(dense_swish(ga(strct, 8, c.w(pm.strct.k), 128, c.w(pm.strct.b), t->sa, 128, 0, B, 8, 128), t->sy, 128));
-    if ((rc = bn_train_fwd(c, t->sy, t->concat, kConcat, 192, B, 128, pm.strct.bn, t->smi))) return rc;
-    T_TRY(t_dropout(t->concat + 192, B, 128, kConcat, 0, seed, 24 + 0, rt.dense, st));
-    // ESM branch (model.py:191-194)
-    T_TRY(dense_swish(ga(esm, kEsm, c.w(pm.esm1.k), 512, c.w(pm.esm1.b), t->ea, 512, 0, B, kEsm, 512), t->ey, 512));
-    if ((rc = bn_train_fwd(c, t->ey, t->e1, 512, 0, B, 512, pm.esm1.bn, t->emi))) return rc;
-    T_TRY(t_dropout(t->e1, B, 512, 512, 0, seed, 24 + 1, rt.dense, st));
-    // swish straight into the concat columns 320..575
-    T_TRY(dense_swish(ga(t->e1, 512, c.w(pm.esm2.k), 256, c.w(pm.esm2.b), t->e2a, 256, 0, B, 512, 256), t->concat + 320, kConcat));
-    for (int b = 0; b < 3; ++b) T_TRY(hipStreamWaitEvent(st, t->ev_join[0][b], 0));   // pooled branch outputs are in concat
-    T_TRY(t_dropout(t->concat, B, kConcat, kConcat, 0, seed, 24 + 2, rt.dense, st));
-    // trunk (model.py:200-205)
-    T_TRY(dense_swish(ga(t->concat, kConcat, c.w(pm.t1.k), 512, c.w(pm.t1.b), t->t1a, 512, 0, B, kConcat, 512), t->t1y, 512));
-    if ((rc = bn_train_fwd(c, t->t1y, t->t1z, 512, 0, B, 512, pm.t1.bn, t->t1mi))) return rc;
-    T_TRY(t_dropout(t->t1z, B, 512, 512, 0, seed, 24 + 3, rt.dense, st));
-    T_TRY(dense_swish(ga(t->t1z, 512, c.w(pm.t2.k), 256, c.w(pm.t2.b), t->t2a, 256, 0, B, 512, 256), t->t2y, 256));
-    if ((rc = bn_train_fwd(c, t->t2y, t->t2z, 256, 0, B, 256, pm.t2.bn, t->t2mi))) return rc;
-    // ---------------- head, loss and its gradient (trainer.py:36-54)
-    T_TRY(t_head_loss(t->t2z, c.w(pm.head.k), c.w(pm.head.b), labels, B, t->d_step, t->proba, t->d_loss, t->d256a,
-                      c.g(pm.head.k), c.g(pm.head.b), st));
-    // ---------------- backward, per-site layers
-    // trunk 2: BN -> swish -> dense
-    if ((rc = bn_train_bwd(c, t->d256a, 256, 0, t->t2y, t->d256b, B, 256, t->t2mi, pm.t2.bn))) return rc;
-    T_TRY(t_swish_bwd(t->t2a, t->d256b, t->d256b, B * 256, st));
-    T_TRY(t_gemm_tn(gt(t->t1z, 512, 0, t->d256b, 256, 0, c.g(pm.t2.k), 256, c.g(pm.t2.b), B, 512, 256), st));
-    T_TRY(t_gemm(ga(t->d256b, 256, c.w(pm.t2.k), 256, nullptr, t->d512a, 512, 0, B, 256, 512), true, st));
-    T_TRY(t_dropout(t->d512a, B, 512, 512, 0, seed, 24 + 3, rt.dense, st));
-    if ((rc = bn_train_bwd(c, t->d512a, 512, 0, t->t1y, t->d512b, B, 512, t->t1mi, pm.t1.bn))) return rc;
-    T_TRY(t_swish_bwd(t->t1a, t->d512b, t->d512b, B * 512, st));
-    T_TRY(t_gemm_tn(gt(t->concat, kConcat, 0, t->d512b, 512, 0, c.g(pm.t1.k), 512, c.g(pm.t1.b), B, kConcat, 512), st));
-    T_TRY(t_gemm(ga(t->d512b, 512, c.w(pm.t1.k), 512, nullptr, t->dconcat, kConcat, 0, B, 512, kConcat), true, st));
-    T_TRY(t_dropout(t->dconcat, B, kConcat, kConcat, 0, seed, 24 + 2, rt.dense, st));
-    // ESM branch: d(concat[:,320:]) -> swish -> dense2 -> dropout -> BN -> swish -> dense1
-    T_TRY(t_copy_cols(t->d256a, 256, 0, t->dconcat, kConcat, 320, B, 256, false, st));
-    T_TRY(t_swish_bwd(t->e2a, t->d256a, t->d256a, B * 256, st));
-    T_TRY(t_gemm_tn(gt(t->e1, 512, 0, t->d256a, 256, 0, c.g(pm.esm2.k), 256, c.g(pm.esm2.b), B, 512, 256), st));
-    T_TRY(t_gemm(ga(t->d256a, 256, c.w(pm.esm2.k), 256, nullptr, t->d512a, 512, 0, B, 256, 512), true, st));
-    T_TRY(t_dropout(t->d512a, B, 512, 512, 0, seed, 24 + 1, rt.dense, st));
-    if ((rc = bn_train_bwd(c, t->d512a, 512, 0, t->ey, t->d512b, B, 512, t->emi, pm.esm1.bn))) return rc;
-    T_TRY(t_swish_bwd(t->ea, t->d512b, t->d512b, B * 512, st));
-    T_TRY(t_gemm_tn(gt(esm, kEsm, 0, t->d512b, 512, 0, c.g(pm.esm1.k), 512, c.g(pm.esm1.b), B, kEsm, 512), st));
-    // struct branch: d(concat[:,192:320]) -> dropout -> BN -> swish -> dense
-    T_TRY(t_copy_cols(t->d128, 128, 0, t->dconcat, kConcat, 192, B, 128, false, st));
-    T_TRY(t_dropout(t->d128, B, 128, 128, 0, seed, 24 + 0, rt.dense, st));
-    if ((rc = bn_train_bwd(c, t->d128, 128, 0, t->sy, t->d512a, B, 128, t->smi, pm.strct.bn))) return rc;
-    T_TRY(t_swish_bwd(t->sa, t->d512a, t->d512a, B * 128, st));
-    T_TRY(t_gemm_tn(gt(strct, 8, 0, t->d512a, 128, 0, c.g(pm.strct.k), 128, c.g(pm.strct.b), B, 8, 128), st));
-    // sequence branches, again side by side (d(concat) is complete; each branch owns its parameters' gradients)
-    T_TRY(hipEventRecord(t->ev_fork[1], st));
-    for (int b = 0; b < 3; ++b) {
-        hipStream_t bs = t->serial ? st : t->aux[b];
-        T_TRY(hipStreamWaitEvent(bs, t->ev_fork[1], 0));
-        Ctx cb{t, bs, t->W, t->G, &t->sc[b]};
-        if ((rc = branch_bwd(cb, b, tok[b], B, seed, rt))) return rc;
-        T_TRY(hipEventRecord(t->ev_join[1][b], bs));
+    auto fork = [&](int phase) -> int {
+        T_TRY(hipEventRecord(t->ev_fork[phase], st));
+        for (int b = 0; b < 2; ++b)
+            if (bstream[b] != st) T_TRY(hipStreamWaitEvent(bstream[b], t->ev_fork[phase], 0));
+        return DPTM_OK;
+    };
+    auto join = [&](int phase) -> int {
+        for (int b = 0; b < 2; ++b)
+            if (bstream[b] != st) {
+                T_TRY(hipEventRecord(t->ev_join[phase][b], bstream[b]));
+                T_TRY(hipStreamWaitEvent(st, t->ev_join[phase][b], 0));
+            }
+        return DPTM_OK;
+    };
+    if ((rc = fork(0))) return rc;
+    if ((rc = branches(true, 0, 1))) return rc;
+    if (small) {
+        const float sc = rt.dense > 0.f ? 1.0f / (1.0f - rt.dense) : 1.0f;
+        const unsigned thr = dropout_threshold(rt.dense);
+        auto dropd = [&](int stream, int cols, int col0) { return SiteDrop{(unsigned)stream, thr, sc, cols, col0}; };
+        const SiteDrop none{0u, 0u, 1.0f, 1, 0};
+        hipStream_t ls = ss;     // stream of the layer launches below
+        auto fwd = [&](const float* x, int64_t ldx, int K, SiteDrop in_drop, const DenseP& L, int N, float* a, bool bn, float* mi,
+                       SiteDrop out_drop, float* out, int64_t ldo, int col_off) {
+            SiteFwdArgs f;
+            f.x = x; f.ldx = ldx; f.K = K; f.in_drop = in_drop;
+            f.W = c.w(L.k); f.bias = c.w(L.b); f.N = N; f.a = a;
+            f.bn = bn ? 1 : 0;
+            f.gamma = bn ? c.w(L.bn.gamma) : nullptr; f.beta = bn ? c.w(L.bn.beta) : nullptr; f.mi = mi;
+            f.batch_mean = bn ? c.g(L.bn.mean) : nullptr; f.batch_var = bn ? c.g(L.bn.var) : nullptr;
+            f.out_drop = out_drop; f.out = out; f.ldo = ldo; f.col_off = col_off;
+            f.B = (int)B; f.step = seed;
+            return t_site_fwd(f, ls);
+        };
+        // struct branch (model.py:187-189), ESM branch (model.py:191-194)
+        T_TRY(fwd(strct, 8, 8, none, pm.strct, 128, t->sa, true, t->smi, dropd(24 + 0, 128, 0), t->concat, kConcat, 192));
+        T_TRY(fwd(esm, kEsm, kEsm, none, pm.esm1, 512, t->ea, true, t->emi, dropd(24 + 1, 512, 0), t->e1, 512, 0));
+        T_TRY(fwd(t->e1, 512, 512, none, pm.esm2, 256, t->e2a, false, nullptr, none, t->concat, kConcat, 320));
+        if ((rc = branches(true, 2, 2))) return rc;
+        if ((rc = join(0))) return rc;              // pooled branch outputs, structure and ESM columns are in concat
+        ls = st;
+        // trunk (model.py:198-205); the dropout in front of it is applied where the concatenation is read
+        T_TRY(fwd(t->concat, kConcat, kConcat, dropd(24 + 2, kConcat, 0), pm.t1, 512, t->t1a, true, t->t1mi, dropd(24 + 3, 512, 0),
+                  t->t1z, 512, 0));
+        T_TRY(fwd(t->t1z, 512, 512, none, pm.t2, 256, t->t2a, true, t->t2mi, none, t->t2z, 256, 0));
+        // head, loss and its gradient (trainer.py:36-54)
+        T_TRY(t_head_loss(t->t2z, c.w(pm.head.k), c.w(pm.head.b), labels, B, t->d_step, t->proba, t->d_loss, t->d256a,
+                          c.g(pm.head.k), c.g(pm.head.b), st));
+        auto bwd = [&](const float* dzd, const float* da_next, int Nn, const DenseP* next, int next_row_off, SiteDrop mid_drop,
+                       float* gout, SiteDrop out_drop, const DenseP* L, bool bn, const float* mi, const float* a, float* da,
+                       const float* x, int64_t ldx, int K, SiteDrop in_drop, int N) {
+            SiteBwdArgs f;
+            f.dzd = dzd; f.ld_dzd = N;
+            f.da_next = da_next; f.W_next = next ? c.w(next->k) : nullptr; f.Nn = Nn; f.next_row_off = next_row_off;
+            f.mid_drop = mid_drop; f.gout = gout; f.ld_gout = kConcat; f.out_drop = out_drop;
+            f.bn = bn ? 1 : 0;
+            f.gamma = bn ? c.w(L->bn.gamma) : nullptr; f.mi = mi; f.a = a; f.da = da;
+            f.x = x; f.ldx = ldx; f.K = K; f.in_drop = in_drop;
+            f.dW = L ? c.g(L->k) : nullptr; f.db = L ? c.g(L->b) : nullptr;
+            f.dgamma = bn ? c.g(L->bn.gamma) : nullptr; f.dbeta = bn ? c.g(L->bn.beta) : nullptr;
+            f.N = N; f.B = (int)B; f.step = seed;
+            return t_site_bwd(f, ls);
+        };
+        T_TRY(bwd(t->d256a, nullptr, 0, nullptr, 0, none, nullptr, none, &pm.t2, true, t->t2mi, t->t2a, t->d256b, t->t1z, 512, 512, none, 256));
+        T_TRY(bwd(nullptr, t->d256b, 256, &pm.t2, 0, none, nullptr, dropd(24 + 3, 512, 0), &pm.t1, true, t->t1mi, t->t1a, t->d512b,
+                  t->concat, kConcat, kConcat, dropd(24 + 2, kConcat, 0), 512));
+        // d(concat) of the three pooled branch outputs (columns 0..191), behind the concatenation's dropout
+        T_TRY(bwd(nullptr, t->d512b, 512, &pm.t1, 0, dropd(24 + 2, kConcat, 0), t->dconcat, none, nullptr, false, nullptr, nullptr, nullptr,
+                  nullptr, 0, 0, none, 192));
+        if ((rc = fork(1))) return rc;
+        if ((rc = branches(false, 0, 1))) return rc;
+        // ESM and structure layers behind the W=21 branch, side by side with the other two
+        ls = ss;
+        T_TRY(bwd(nullptr, t->d512b, 512, &pm.t1, 320, dropd(24 + 2, kConcat, 320), nullptr, none, &pm.esm2, false, nullptr, t->e2a, t->d256a,
+                  t->e1, 512, 512, none, 256));
+        T_TRY(bwd(nullptr, t->d512b, 512, &pm.t1, 192, dropd(24 + 2, kConcat, 192), nullptr, dropd(24 + 0, 128, 0), &pm.strct, true, t->smi,
+                  t->sa, t->d128, strct, 8, 8, none, 128));
+        T_TRY(bwd(nullptr, t->d256a, 256, &pm.esm2, 0, none, nullptr, dropd(24 + 1, 512, 0), &pm.esm1, true, t->emi, t->ea, t->d512a, esm, kEsm,
+                  kEsm, none, 512));
+        if ((rc = branches(false, 2, 2))) return rc;
+    } else {
+        // struct branch (model.py:187-189)
+        auto dense_swish = [&](GemmArgs g, float* act, int64_t lda) {     // pre-activation to g.out, swish of it to act
+            g.act_out = act; g.lda = lda;
+            return t_gemm(g, false, st);
+        };
+        T_TRY(dense_swish(ga(strct, 8, c.w(pm.strct.k), 128, c.w(pm.strct.b), t->sa, 128, 0, B, 8, 128), t->sy, 128));
+        if ((rc = bn_train_fwd(c, t->sy, t->concat, kConcat, 192, B, 128, pm.strct.bn, t->smi))) return rc;
+        T_TRY(t_dropout(t->concat + 192, B, 128, kConcat, 0, seed, 24 + 0, rt.dense, st));
+        // ESM branch (model.py:191-194)
+        T_TRY(dense_swish(ga(esm, kEsm, c.w(pm.esm1.k), 512, c.w(pm.esm1.b), t->ea, 512, 0, B, kEsm, 512), t->ey, 512));
+        if ((rc = bn_train_fwd(c, t->ey, t->e1, 512, 0, B, 512, pm.esm1.bn, t->emi))) return rc;
+        T_TRY(t_dropout(t->e1, B, 512, 512, 0, seed, 24 + 1, rt.dense, st));
+        // swish straight into the concat columns 320..575
+        T_TRY(dense_swish(ga(t->e1, 512, c.w(pm.esm2.k), 256, c.w(pm.esm2.b), t->e2a, 256, 0, B, 512, 256), t->concat + 320, kConcat));
+        if ((rc = branches(true, 2, 2))) return rc;
+        if ((rc = join(0))) return rc;              // pooled branch outputs are in concat
+        T_TRY(t_dropout(t->concat, B, kConcat, kConcat, 0, seed, 24 + 2, rt.dense, st));
+        // trunk (model.py:200-205)
+        T_TRY(dense_swish(ga(t->concat, kConcat, c.w(pm.t1.k), 512, c.w(pm.t1.b), t->t1a, 512, 0, B, kConcat, 512), t->t1y, 512));
+        if ((rc = bn_train_fwd(c, t->t1y, t->t1z, 512, 0, B, 512, pm.t1.bn, t->t1mi))) return rc;
+        T_TRY(t_dropout(t->t1z, B, 512, 512, 0, seed, 24 + 3, rt.dense, st));
+        T_TRY(dense_swish(ga(t->t1z, 512, c.w(pm.t2.k), 256, c.w(pm.t2.b), t->t2a, 256, 0, B, 512, 256), t->t2y, 256));
+        if ((rc = bn_train_fwd(c, t->t2y, t->t2z, 256, 0, B, 256, pm.t2.bn, t->t2mi))) return rc;
+        // ---------------- head, loss and its gradient (trainer.py:36-54)
+        T_TRY(t_head_loss(t->t2z, c.w(pm.head.k), c.w(pm.head.b), labels, B, t->d_step, t->proba, t->d_loss, t->d256a,
+                          c.g(pm.head.k), c.g(pm.head.b), st));
+        // ---------------- backward, per-site layers
+        // trunk 2: BN -> swish -> dense
+        if ((rc = bn_train_bwd(c, t->d256a, 256, 0, t->t2y, t->d256b, B, 256, t->t2mi, pm.t2.bn))) return rc;
+        T_TRY(t_swish_bwd(t->t2a, t->d256b, t->d256b, B * 256, st));
+        T_TRY(t_gemm_tn(gt(t->t1z, 512, 0, t->d256b, 256, 0, c.g(pm.t2.k), 256, c.g(pm.t2.b), B, 512, 256), st));
+        T_TRY(t_gemm(ga(t->d256b, 256, c.w(pm.t2.k), 256, nullptr, t->d512a, 512, 0, B, 256, 512), true, st));
+        T_TRY(t_dropout(t->d512a, B, 512, 512, 0, seed, 24 + 3, rt.dense, st));
+        if ((rc = bn_train_bwd(c, t->d512a, 512, 0, t->t1y, t->d512b, B, 512, t->t1mi, pm.t1.bn))) return rc;
+        T_TRY(t_swish_bwd(t->t1a, t->d512b, t->d512b, B * 512, st));
+        T_TRY(t_gemm_tn(gt(t->concat, kConcat, 0, t->d512b, 512, 0, c.g(pm.t1.k), 512, c.g(pm.t1.b), B, kConcat, 512), st));
+        T_TRY(t_gemm(ga(t->d512b, 512, c.w(pm.t1.k), 512, nullptr, t->dconcat, kConcat, 0, B, 512, kConcat), true, st));
+        T_TRY(t_dropout(t->dconcat, B, kConcat, kConcat, 0, seed, 24 + 2, rt.dense, st));
+        // d(concat) is complete: the sequence branches go backward side by side with the ESM and structure layers below
+        // (each owns its parameters' gradients)
+        if ((rc = fork(1))) return rc;
+        if ((rc = branches(false, 0, 2))) return rc;
+        // ESM branch: d(concat[:,320:]) -> swish -> dense2 -> dropout -> BN -> swish -> dense1
+        T_TRY(t_copy_cols(t->d256a, 256, 0, t->dconcat, kConcat, 320, B, 256, false, st));
+        T_TRY(t_swish_bwd(t->e2a, t->d256a, t->d256a, B * 256, st));
+        T_TRY(t_gemm_tn(gt(t->e1, 512, 0, t->d256a, 256, 0, c.g(pm.esm2.k), 256, c.g(pm.esm2.b), B, 512, 256), st));
+        T_TRY(t_gemm(ga(t->d256a, 256, c.w(pm.esm2.k), 256, nullptr, t->d512a, 512, 0, B, 256, 512), true, st));
+        T_TRY(t_dropout(t->d512a, B, 512, 512, 0, seed, 24 + 1, rt.dense, st));
+        if ((rc = bn_train_bwd(c, t->d512a, 512, 0, t->ey, t->d512b, B, 512, t->emi, pm.esm1.bn))) return rc;
+        T_TRY(t_swish_bwd(t->ea, t->d512b, t->d512b, B * 512, st));
+        T_TRY(t_gemm_tn(gt(esm, kEsm, 0, t->d512b, 512, 0, c.g(pm.esm1.k), 512, c.g(pm.esm1.b), B, kEsm, 512), st));
+        // struct branch: d(concat[:,192:320]) -> dropout -> BN -> swish -> dense
+        T_TRY(t_copy_cols(t->d128, 128, 0, t->dconcat, kConcat, 192, B, 128, false, st));
+        T_TRY(t_dropout(t->d128, B, 128, 128, 0, seed, 24 + 0, rt.dense, st));
+        if ((rc = bn_train_bwd(c, t->d128, 128, 0, t->sy, t->d512a, B, 128, t->smi, pm.strct.bn))) return rc;
+        T_TRY(t_swish_bwd(t->sa, t->d512a, t->d512a, B * 128, st));
+        T_TRY(t_gemm_tn(gt(strct, 8, 0, t->d512a, 128, 0, c.g(pm.strct.k), 128, c.g(pm.strct.b), B, 8, 128), st));
     }
-    for (int b = 0; b < 3; ++b) T_TRY(hipStreamWaitEvent(st, t->ev_join[1][b], 0));
+    if ((rc = join(1))) return rc;
     // l2 kernel regularisers (model.py:130-138,200,204): value into the loss, 2*lambda*w into the gradient
     if (o->l2 > 0.f) {
         L2Segs segs;
@@ -722,6 +820,10 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
                 segs.n += 1;
             }
         T_TRY(t_l2(t->W, t->G, segs, o->l2 * o->l2_scale, t->d_loss, st));
+    }
+    if (st != caller) {
+        T_TRY(hipEventRecord(t->ev_caller[1], st));
+        T_TRY(hipStreamWaitEvent(caller, t->ev_caller[1], 0));
     }
     return DPTM_OK;
 }

@@ -379,8 +379,22 @@ constexpr int kSPoolW = 2 * kSlotsPerBlock, kSPoolB = kSPoolW + 1;
 constexpr int kSBn2A = 13, kSBn2B = 27;     // the two spare slots: sum d(x1), sum d(x1) * swish(a2)
 static_assert(kSPoolB < kTbVecs, "vector slots");
 
-template <int W>
-__global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
+// (experiment builds only: DPTM_EXP_NOSYNC drops the barriers of the tile loop to price them; results are then wrong)
+#ifdef DPTM_EXP_HOTLOADS
+#define CTL(ct) ((int64_t)lane)     // experiment: every tile reads the same cache-resident rows
+#else
+#define CTL(ct) (ct)
+#endif
+#ifdef DPTM_EXP_NOSYNC
+#define TB_SYNC() wave_fence()
+#else
+#define TB_SYNC() __syncthreads()
+#endif
+
+// MAXT: the largest workgroup the instance is launched with.  Tiles of up to four wavefronts get an instance of their
+// own whose register budget is twice that of the eight-wavefront tile (one wavefront per SIMD instead of two).
+template <int W, int MAXT>
+__global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int NW = blockDim.x >> 6, rows_tile = NW * 32;
     const int img = img_floats(NW);                  // room for a row-major [rows][68] or a transposed [64][rows + 4] image
@@ -418,14 +432,14 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
         const int64_t ct = ((tile * NW + wave) * 8) * 64 + lane;
         const int64_t cl = (tile * NW + wave) * 64 + lane;
         f32x4 dy[8];   // gradient w.r.t. the output of the block in hand
-        __syncthreads();   // the previous tile's last exchange through xreg has been read
+        TB_SYNC();   // the previous tile's last exchange through xreg has been read
         // ---- attention pooling backward: dx_t = alpha_t dout + dz_t w, dz_t = alpha_t (dalpha_t - sum alpha dalpha)(1 - a_t^2)
         {
             const f32x4* tv1 = p.P + kOffTb + kTbSize + kTbVec;
             const f32x4* pv = p.P + kOffPoolV;
             f32x4 x[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = p.sv[1].xh2[ct + u * 64];
+            for (int u = 0; u < 8; ++u) x[u] = p.sv[1].xh2[CTL(ct) + u * 64];
             ln_affine(x, tv1 + kVLn2G * kVec64, tv1 + kVLn2B * kVec64, h, x);
             const f32x2 pa = p.pool[cl];
             const float* dsite = p.dout + (site0 + row / W) * p.ldd + p.col_off;
@@ -440,7 +454,7 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
             }
             dal = xhalf_sum(dal);
             if (h == 0) xreg[row] = row_ok ? pa[1] * dal : 0.f;
-            __syncthreads();
+            TB_SYNC();
             float dot = 0.f;
 #pragma unroll 3
             for (int t = 0; t < W; ++t) dot += xreg[att_start + t];
@@ -460,7 +474,7 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
             for (int o = 32; o > 0; o >>= 1) dzs += __shfl_xor(dzs, o);
             if (lane == 0) atomicAdd(&vacc[kSPoolB * 64], dzs);
             wave_fence();
-            __syncthreads();   // the scores in xreg have been read
+            TB_SYNC();   // the scores in xreg have been read
         }
         PH_MARK(0)   // pooling backward
 #pragma unroll 1
@@ -477,7 +491,7 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
             {
                 f32x4 xh[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) xh[u] = sv.xh2[ct + u * 64];
+                for (int u = 0; u < 8; ++u) xh[u] = sv.xh2[CTL(ct) + u * 64];
                 ln_backward(dy, xh, iv[1], tv + kVLn2G * kVec64, h, dsum, lane_a, lane_b);
                 wave_fence();
                 atomicAdd(va + kSG2 * 64, colsum32_t(bufA, row0, lane));
@@ -493,7 +507,7 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
             {
                 f32x4 xh[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) xh[u] = sv.xh1[ct + u * 64];
+                for (int u = 0; u < 8; ++u) xh[u] = sv.xh1[CTL(ct) + u * 64];
                 ln_affine(xh, tv + kVLn1G * kVec64, tv + kVLn1B * kVec64, h, hx);
             }
             // ---- feed-forward layers backward; the hidden layer is rebuilt in four 64-wide chunks
@@ -535,7 +549,7 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                     atomicAdd(va + kSFb2 * 64, colsum32_t(bufB, row0, lane));
                 }
                 PH_MARK(2)   // feed-forward row products
-                __syncthreads();
+                TB_SYNC();
                 dw_unit_t(bufA, bufB, NW, xreg, pu + (4 + c) * 4096, first, lane, wave);     // dW2[chunk, :] += u_c^T d(f2)
                 PH_MARK(3)   // feed-forward weight gradients
                 chain_store_t(lane_a, hx);
@@ -544,7 +558,7 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                 atomicAdd(va + (kSFb1 + c) * 64, colsum32_t(bufB, row0, lane));
                 gemm_k256_chunk(acc_dh, TT + kBtW1T, c, d1, lane);                         // d(h) += d(f1_c) W1[:, chunk]^T
                 PH_MARK(2)
-                __syncthreads();
+                TB_SYNC();
                 dw_unit_t(bufA, bufB, NW, xreg, pu + c * 4096, first, lane, wave);           // dW1[:, chunk] += h^T d(f1_c)
                 PH_MARK(3)
             }
@@ -554,7 +568,7 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                 f32x4 dh[8], xh[8];
                 acc_to_x<2>(acc_dh, dh);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) xh[u] = sv.xh1[ct + u * 64];
+                for (int u = 0; u < 8; ++u) xh[u] = sv.xh1[CTL(ct) + u * 64];
                 ln_backward(dh, xh, iv[0], tv + kVLn1G * kVec64, h, dsum, lane_a, lane_b);
                 wave_fence();
                 atomicAdd(va + kSG1 * 64, colsum32_t(bufA, row0, lane));
@@ -570,14 +584,14 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     dao[u] = dsum[u];
-                    o[u] = sv.o[ct + u * 64];
+                    o[u] = sv.o[CTL(ct) + u * 64];
                 }
                 dropout_chain(dao, grow, h, seed, p.stream_base + 2 * blk, p.thr, p.scale);
                 chain_store_t(lane_a, o);
                 chain_store_t(lane_b, dao);
                 wave_fence();
                 atomicAdd(va + kSBo * 64, colsum32_t(bufB, row0, lane));
-                __syncthreads();
+                TB_SYNC();
                 dw_unit_t(bufA, bufB, NW, xreg, pu + 8 * 4096, first, lane, wave);           // dWo += o^T d(ao)
                 f32x16 acc[2];
                 acc_zero<2>(acc);
@@ -604,17 +618,17 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                 {
                     f32x4 t[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = sv.k[ct + u * 64];
+                    for (int u = 0; u < 8; ++u) t[u] = sv.k[CTL(ct) + u * 64];
                     chain_store(mine_a, h, t);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = sv.v[ct + u * 64];
+                    for (int u = 0; u < 8; ++u) t[u] = sv.v[CTL(ct) + u * 64];
                     chain_store(mine_b, h, t);
                     float qs[2][16], doh[2][16], gh[2][16];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = sv.q[ct + u * 64];
+                    for (int u = 0; u < 8; ++u) t[u] = sv.q[CTL(ct) + u * 64];
                     x_to_heads(t, qs, kQScale);
                     x_to_heads(dO, doh, 1.0f);
-                    __syncthreads();   // K and V of the tile are in LDS
+                    TB_SYNC();   // K and V of the tile are in LDS
 #pragma unroll
                     for (int hd = 0; hd < 2; ++hd) {
                         const int off = att_start * kLdsStride + 32 * h + 16 * hd;
@@ -623,16 +637,16 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                     heads_to_x(gh, dq, row_ok ? 0.25f : 0.f);
                 }
                 PH_MARK(6)   // attention backward, query rows
-                __syncthreads();   // K and V have been read
+                TB_SYNC();   // K and V have been read
                 PH_MARK(10)  // barrier after a vector-unit phase
                 {
                     f32x4 xin[8];
                     if (blk == 0) {
-                        x1_from_conv(p.cs, ct, bnv, h, row_ok, xin);
+                        x1_from_conv(p.cs, CTL(ct), bnv, h, row_ok, xin);
                     } else {
                         const f32x4* tv0 = p.P + kOffTb + kTbVec;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) xin[u] = p.sv[0].xh2[ct + u * 64];
+                        for (int u = 0; u < 8; ++u) xin[u] = p.sv[0].xh2[CTL(ct) + u * 64];
                         ln_affine(xin, tv0 + kVLn2G * kVec64, tv0 + kVLn2B * kVec64, h, xin);
                     }
                     chain_store_t(lane_a, xin);
@@ -640,7 +654,7 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                 chain_store_t(lane_b, dq);
                 wave_fence();
                 atomicAdd(va + kSBq * 64, colsum32_t(bufB, row0, lane));
-                __syncthreads();
+                TB_SYNC();
                 dw_unit_t(bufA, bufB, NW, xreg, pu + 9 * 4096, first, lane, wave);           // dWq += x^T dq
                 x_to_acc(dsum, acc_dx);
                 gemm_regs<8, 2>(acc_dx, TT + kBtWqT, dq, lane);
@@ -652,7 +666,7 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                 {
                     f32x4 t[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = sv.q[ct + u * 64] * kQScale;
+                    for (int u = 0; u < 8; ++u) t[u] = sv.q[CTL(ct) + u * 64] * kQScale;
                     chain_store(mine_a, h, t);
                     chain_store(mine_b, h, dO);
 #pragma unroll
@@ -663,12 +677,12 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                     }
                     float kh[2][16], vh[2][16], gk[2][16], gv[2][16];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = sv.k[ct + u * 64];
+                    for (int u = 0; u < 8; ++u) t[u] = sv.k[CTL(ct) + u * 64];
                     x_to_heads(t, kh, 1.0f);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = sv.v[ct + u * 64];
+                    for (int u = 0; u < 8; ++u) t[u] = sv.v[CTL(ct) + u * 64];
                     x_to_heads(t, vh, 1.0f);
-                    __syncthreads();   // scaled Q, dO and the statistics of the tile are in LDS
+                    TB_SYNC();   // scaled Q, dO and the statistics of the tile are in LDS
 #pragma unroll
                     for (int hd = 0; hd < 2; ++hd) {
                         const int off = att_start * kLdsStride + 32 * h + 16 * hd;
@@ -679,16 +693,16 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                     heads_to_x(gv, dv, row_ok ? 1.0f : 0.f);
                 }
                 PH_MARK(8)   // attention backward, key rows
-                __syncthreads();   // Q and dO have been read
+                TB_SYNC();   // Q and dO have been read
                 PH_MARK(10)
                 {
                     f32x4 xin[8];
                     if (blk == 0) {
-                        x1_from_conv(p.cs, ct, bnv, h, row_ok, xin);
+                        x1_from_conv(p.cs, CTL(ct), bnv, h, row_ok, xin);
                     } else {
                         const f32x4* tv0 = p.P + kOffTb + kTbVec;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) xin[u] = p.sv[0].xh2[ct + u * 64];
+                        for (int u = 0; u < 8; ++u) xin[u] = p.sv[0].xh2[CTL(ct) + u * 64];
                         ln_affine(xin, tv0 + kVLn2G * kVec64, tv0 + kVLn2B * kVec64, h, xin);
                     }
                     chain_store_t(lane_a, xin);
@@ -696,13 +710,13 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
                 chain_store_t(lane_b, dk);
                 wave_fence();
                 atomicAdd(va + kSBk * 64, colsum32_t(bufB, row0, lane));
-                __syncthreads();
+                TB_SYNC();
                 dw_unit_t(bufA, bufB, NW, xreg, pu + 10 * 4096, first, lane, wave);          // dWk += x^T dk
                 gemm_regs<8, 2>(acc_dx, TT + kBtWkT, dk, lane);
                 chain_store_t(lane_b, dv);
                 wave_fence();
                 atomicAdd(va + kSBv * 64, colsum32_t(bufB, row0, lane));
-                __syncthreads();
+                TB_SYNC();
                 dw_unit_t(bufA, bufB, NW, xreg, pu + 11 * 4096, first, lane, wave);          // dWv += x^T dv
                 gemm_regs<8, 2>(acc_dx, TT + kBtWvT, dv, lane);
             }
@@ -715,7 +729,7 @@ __global__ __launch_bounds__(512) void tb_bwd_kernel(TbBwdArgs p) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 p.dx1[ct + u * 64] = dy[u];
-                const f32x4 a = p.cs.a2[ct + u * 64];
+                const f32x4 a = p.cs.a2[CTL(ct) + u * 64];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) t[u][e] = dy[u][e] * swishf(a[e]);
             }
@@ -816,10 +830,16 @@ hipError_t t_tb_fwd(const TbFwdArgs& a, int wlen, int NW, hipStream_t st) {
 
 template <int W>
 static hipError_t launch_bwd(const TbBwdArgs& a, int NW, int grid, hipStream_t st) {
-    static bool done[64] = {};
-    hipError_t e = lds_opt_in(&tb_bwd_kernel<W>, done, bwd_lds(8));
+    static bool done[64] = {}, done_small[64] = {};
+    if (NW <= 4) {
+        hipError_t e = lds_opt_in(&tb_bwd_kernel<W, 256>, done_small, bwd_lds(4));
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((tb_bwd_kernel<W, 256>), dim3((unsigned)grid), dim3(64 * NW), bwd_lds(NW), st, a);
+        return hipGetLastError();
+    }
+    hipError_t e = lds_opt_in(&tb_bwd_kernel<W, 512>, done, bwd_lds(8));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tb_bwd_kernel<W>, dim3((unsigned)grid), dim3(64 * NW), bwd_lds(NW), st, a);
+    hipLaunchKernelGGL((tb_bwd_kernel<W, 512>), dim3((unsigned)grid), dim3(64 * NW), bwd_lds(NW), st, a);
     return hipGetLastError();
 }
 

@@ -278,4 +278,58 @@ hipError_t t_conv_b_fwd(const ConvArgs& a, int wlen, int NW, hipStream_t st);   
 hipError_t t_conv_b_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW, hipStream_t st);   // dx1 -> dz1, conv3b / BN2 gradients
 hipError_t t_conv_a_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW, hipStream_t st);   // dz1, dx1 -> conv3a / shortcut / BN1 / embedding gradients
 
+
+// ---- per-site dense layers for small batches (dptm_train_site.hip)
+constexpr int kSiteMaxRows = 128;
+// inverted dropout on the stateless hash: element (row r, column c) has index r*cols + col0 + c; thr 0: none
+struct SiteDrop {
+    unsigned stream, thr;
+    float scale;
+    int cols, col0;
+};
+struct SiteFwdArgs {
+    const float* x;          // [B][ldx], K columns used, in_drop applied on load
+    int64_t ldx;
+    int K;
+    SiteDrop in_drop;
+    const float *W, *bias;   // raw [K][N], [N]
+    int N;
+    float* a;                // [B][N] pre-activation, kept for the backward pass
+    int bn;                  // BatchNormalization (batch statistics) behind the swish
+    const float *gamma, *beta;
+    float* mi;               // [mean | 1/sigma] of the batch, 2N floats
+    float *batch_mean, *batch_var;
+    SiteDrop out_drop;
+    float* out;              // out[r*ldo + col_off + c]
+    int64_t ldo;
+    int col_off;
+    int B;
+    const unsigned* step;
+};
+hipError_t t_site_fwd(const SiteFwdArgs& a, hipStream_t st);
+struct SiteBwdArgs {
+    // gradient w.r.t. the layer's output as the next layer saw it: read from dzd[r*ld_dzd + c], or (dzd == nullptr)
+    // formed as sum_n da_next[r][n] * W_next[(next_row_off + c)*Nn + n]
+    const float* dzd;
+    int64_t ld_dzd;
+    const float *da_next, *W_next;
+    int Nn, next_row_off;
+    SiteDrop mid_drop;       // the next layer's input dropout (columns counted from this layer's column 0)
+    float* gout;             // optional: the gradient behind mid_drop is stored here (gout[r*ld_gout + c])
+    int64_t ld_gout;
+    SiteDrop out_drop;       // this layer's own output dropout
+    int bn;
+    const float *gamma, *mi;
+    const float* a;          // nullptr: no layer below the gradient (only gout is written)
+    float* da;               // [B][N] gradient w.r.t. the pre-activation, read by the layer below
+    const float* x;          // the layer's input, as in the forward pass
+    int64_t ldx;
+    int K;
+    SiteDrop in_drop;
+    float *dW, *db, *dgamma, *dbeta;   // gradients (raw layouts), added to
+    int N, B;
+    const unsigned* step;
+};
+hipError_t t_site_bwd(const SiteBwdArgs& a, hipStream_t st);
+
 }  // namespace dptm

@@ -259,6 +259,11 @@ __device__ __forceinline__ void dw_unit(const float* imgX, const float* imgY, in
     }
 }
 
+#ifdef DPTM_EXP_NOSYNC
+#define DW_SYNC() wave_fence()
+#else
+#define DW_SYNC() __syncthreads()
+#endif
 // dw_unit on transposed images: one 16-byte read per operand feeds four MFMA steps.  Step s of group Q contracts
 // rows 8Q + s (lower half-wave) and 8Q + 4 + s (upper half-wave); every row of the tile is met once.
 __device__ __forceinline__ void dw_unit_t(const float* imgXT, const float* imgYT, int NW, float* xchg,
@@ -300,7 +305,7 @@ __device__ __forceinline__ void dw_unit_t(const float* imgXT, const float* imgYT
 #pragma unroll
                 for (int rg = 0; rg < 16; ++rg) xchg[(b * 16 + rg) * 64 + lane] = acc[rg];
             }
-            __syncthreads();
+            DW_SYNC();
             if (sp == 0) {
 #pragma unroll
                 for (int rg = 0; rg < 16; ++rg) acc[rg] += xchg[(b * 16 + rg) * 64 + lane];
@@ -311,7 +316,7 @@ __device__ __forceinline__ void dw_unit_t(const float* imgXT, const float* imgYT
             for (int rg = 0; rg < 16; ++rg) dst[rg * 64] = acc[rg] + prev[rg];
         }
     }
-    if (NW != 8) __syncthreads();
+    if (NW != 8) DW_SYNC();
 }
 
 // scale | shift of a BatchNormalization in training mode from the column sums of its input (keras epsilon 1e-3,
