@@ -32,6 +32,7 @@ EXPORTS = (
     "dptm_set_precision", "dptm_trainer_create", "dptm_trainer_destroy", "dptm_trainer_forward_backward",
     "dptm_trainer_grad_buffer", "dptm_trainer_param_floats", "dptm_trainer_apply",
     "dptm_trainer_get_weights", "dptm_trainer_get_grads", "dptm_trainer_get_proba",
+    "dptm_trainer_get_optimizer_state", "dptm_trainer_set_optimizer_state",
     "dptm_trainer_last_error", "dptm_trainer_set_allreduce", "dptm_sasa", "dptm_sasa_last_error",
 )
 
@@ -171,6 +172,10 @@ def load_library() -> C.CDLL:
         getattr(lib, name).argtypes = [vp, f32p]
     lib.dptm_trainer_get_proba.restype = C.c_int
     lib.dptm_trainer_get_proba.argtypes = [vp, f32p, i64]
+    lib.dptm_trainer_get_optimizer_state.restype = C.c_int
+    lib.dptm_trainer_get_optimizer_state.argtypes = [vp, f32p, f32p, C.POINTER(i64)]
+    lib.dptm_trainer_set_optimizer_state.restype = C.c_int
+    lib.dptm_trainer_set_optimizer_state.argtypes = [vp, f32p, f32p, i64]
     lib.dptm_trainer_set_allreduce.restype = C.c_int
     lib.dptm_trainer_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
     lib.dptm_trainer_last_error.restype = C.c_char_p
@@ -453,6 +458,23 @@ class Trainer:
         out = np.empty(self.n_canonical, dtype=np.float32)
         _check_t(self._lib, self._lib.dptm_trainer_get_grads(self._h, _ptr(out)), "dptm_trainer_get_grads")
         return out
+
+    def get_optimizer_state(self):
+        """(m, v, step): Adam moments in the canonical blob order and the number of steps taken."""
+        m = np.empty(self.n_canonical, dtype=np.float32)
+        v = np.empty(self.n_canonical, dtype=np.float32)
+        step = C.c_int64(0)
+        _check_t(self._lib, self._lib.dptm_trainer_get_optimizer_state(self._h, _ptr(m), _ptr(v), C.byref(step)),
+                 "dptm_trainer_get_optimizer_state")
+        return m, v, int(step.value)
+
+    def set_optimizer_state(self, m: np.ndarray, v: np.ndarray, step: int) -> None:
+        m = np.ascontiguousarray(m, dtype=np.float32)
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        if m.size != self.n_canonical or v.size != self.n_canonical:
+            raise ValueError("optimizer moments must hold one float per weight of the canonical blob")
+        _check_t(self._lib, self._lib.dptm_trainer_set_optimizer_state(self._h, _ptr(m), _ptr(v), int(step)),
+                 "dptm_trainer_set_optimizer_state")
 
     def get_proba(self, n: int) -> np.ndarray:
         out = np.empty((n, 2), dtype=np.float32)

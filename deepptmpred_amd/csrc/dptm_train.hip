@@ -950,6 +950,35 @@ int dptm_trainer_get_grads(dptm_trainer* t, float* host_out) try {
 } catch (...) {
     return on_texception("dptm_trainer_get_grads");
 }
+static int copy_in(dptm_trainer* t, float* dev, const float* host_canonical) {
+    std::vector<float> host((size_t)t->pm.total, 0.0f);
+    for (const Tn& x : t->pm.t) std::memcpy(host.data() + x.off, host_canonical + x.canon, (size_t)x.size * sizeof(float));
+    T_TRY(hipSetDevice(t->device));
+    T_TRY(hipDeviceSynchronize());
+    T_TRY(hipMemcpy(dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    return DPTM_OK;
+}
+
+int dptm_trainer_get_optimizer_state(dptm_trainer* t, float* m_host_out, float* v_host_out, int64_t* step_out) try {
+    if (!t || !m_host_out || !v_host_out || !step_out) return tfail(DPTM_EINVAL, "dptm_trainer_get_optimizer_state: NULL argument");
+    int rc = copy_out(t, t->M, m_host_out);
+    if (rc) return rc;
+    if ((rc = copy_out(t, t->V, v_host_out))) return rc;
+    *step_out = t->step;
+    return DPTM_OK;
+} catch (...) {
+    return on_texception("dptm_trainer_get_optimizer_state");
+}
+int dptm_trainer_set_optimizer_state(dptm_trainer* t, const float* m_host, const float* v_host, int64_t step) try {
+    if (!t || !m_host || !v_host || step < 0) return tfail(DPTM_EINVAL, "dptm_trainer_set_optimizer_state: bad argument");
+    int rc = copy_in(t, t->M, m_host);
+    if (rc) return rc;
+    if ((rc = copy_in(t, t->V, v_host))) return rc;
+    t->step = step;
+    return DPTM_OK;
+} catch (...) {
+    return on_texception("dptm_trainer_set_optimizer_state");
+}
 int dptm_trainer_get_proba(dptm_trainer* t, float* host_out, int64_t n) try {
     if (!t || !host_out || n < 0 || n > t->max_batch) return tfail(DPTM_EINVAL, "dptm_trainer_get_proba: bad argument");
     T_TRY(hipSetDevice(t->device));

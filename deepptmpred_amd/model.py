@@ -176,13 +176,22 @@ class Model:
         if getattr(self, "_optimizer", None) is None:
             raise RuntimeError("call compile() before training")
         if getattr(self, "_dp", None) is None or self._dp_batch < batch_size:
+            # A larger batch needs a larger trainer.  The reference keeps one optimizer for all of fit()
+            # (trainer.py:304-309): Adam's moments, the step count behind its bias correction and the step counter
+            # the dropout seeds follow move over to the new trainer.
+            carried = None
             if getattr(self, "_dp", None) is not None:
+                carried = (self._dp.backend.trainer.get_optimizer_state(), self._dp.steps)
                 self._pull_trained_weights()
                 self._dp.backend.close()
             backend = NativeBackend(self._weights, self.spec, self.device, max_batch=batch_size)
             self._dp = DataParallelTrainer(backend, self._optimizer,
                                            DropoutRates(self.spec.weight_decay, self.spec.dropout_rate, 0.1,
                                                         self.spec.dropout_rate), l2=self.spec.weight_decay)
+            if carried is not None:
+                (m, v, step), steps = carried
+                backend.trainer.set_optimizer_state(m, v, step)
+                self._dp.steps = steps
             self._dp_batch = batch_size
         return self._dp
 

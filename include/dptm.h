@@ -288,6 +288,12 @@ int dptm_trainer_set_allreduce(dptm_trainer* t, dptm_allreduce_fn fn, void* user
 int dptm_trainer_get_weights(dptm_trainer* t, float* host_out);
 int dptm_trainer_get_grads(dptm_trainer* t, float* host_out);
 int dptm_trainer_get_proba(dptm_trainer* t, float* host_out, int64_t n);
+/* The optimizer's state -- Adam's first and second moments in the canonical blob order (dptm_weight_count floats each)
+ * and the count of steps taken (it sets the bias correction) -- so that a trainer that is rebuilt, for a larger
+ * batch say, carries on where the old one stopped.  The reference keeps ONE optimizer object for the whole of
+ * model.fit (pred/train_PTM/trainer.py:304-309, 332-339). */
+int dptm_trainer_get_optimizer_state(dptm_trainer* t, float* m_host_out, float* v_host_out, int64_t* step_out);
+int dptm_trainer_set_optimizer_state(dptm_trainer* t, const float* m_host, const float* v_host, int64_t step);
 const char* dptm_trainer_last_error(void);
 
 

@@ -116,6 +116,26 @@ def test_keras_like_fit_reduces_loss_and_updates_predictions():
     m.close()
 
 
+def test_growing_batch_keeps_the_optimizer_state():
+    """A batch larger than the trainer was built for rebuilds the trainer; Adam's moments, its step count and the
+    step counter behind the dropout seeds carry over (one optimizer for the whole of fit, trainer.py:304-309)."""
+    from deepptmpred_amd.model import create_ptm_model
+    from deepptmpred_amd.training import AdamW
+    m = create_ptm_model(seed=5)
+    m.compile(optimizer=AdamW(learning_rate=5e-4, weight_decay=1e-4), loss=None)
+    x = spec.synthetic_inputs(96, 31)
+    y = (x[3][:, 0] > 125).astype(np.int64)
+    m.train_on_batch([a[:32] for a in x], np.eye(2)[y[:32]])
+    m0, v0, s0 = m._dp.backend.trainer.get_optimizer_state()
+    assert s0 == 1 and np.abs(m0).max() > 0 and np.abs(v0).max() > 0
+    m.train_on_batch(x, np.eye(2)[y])                     # 96 > 32: a new, larger trainer
+    m1, v1, s1 = m._dp.backend.trainer.get_optimizer_state()
+    assert s1 == 2 and m._dp.steps == 2
+    # second moments only decay by 0.999 per step and grow by g^2: they cannot fall below 0.999 * v0
+    assert (v1 >= 0.999 * v0 - 1e-12).all() and np.abs(m1 - m0).max() > 0
+    m.close()
+
+
 def test_fit_with_validation_and_reference_callbacks(tmp_path):
     """The callback set of trainer.py:311-328 around the native step: validation metrics per epoch,
     early stopping on val_auc with the best weights put back, best-only checkpoints, a CSV log."""
