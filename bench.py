@@ -56,7 +56,15 @@ PEAK_MFMA = {"f32": PEAK_F32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS, "f16": 
 KERNEL_NAME = {"f32": "branch_kernel<51>", "f16x3": "branch_kernel_h<51,f16x3>", "f16": "branch_kernel_h<51,f16>",
                "bf16": "branch_kernel_h<51,bf16>"}
 TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r2_pmc_traffic.json", "r1_pmc_traffic.json")]
+ISSUE_FILES = [os.path.join(ROOT, "profiles", "r2_pmc_summary.json")]
+TRAIN_TRAFFIC_FILES = [os.path.join(ROOT, "profiles", "r2_train_pmc_traffic.json")]
 PEAK_HBM_GBS = 8000.0
+N_SIMD = 1024                        # 256 CUs x 4 SIMDs
+PEAK_CLOCK_GHZ = 2.4
+# contractions of both TransformerBlocks and the attention pooling per site of a W-row window (forward):
+# per row and block 3 x 64x64 (q, k, v) + 64x64 (out) + 2 x 64x256 (FFN) + 2 x W x 64 (scores, mix); the backward
+# pass has two products per forward product (input and weight gradient; dP, dV, dQ, dK for the attention)
+TB_FWD_FLOPS = {w: w * (2 * (98304 + 256 * w) + 256) for w in (21, 33, 51)}
 
 
 def measured_traffic(precision: str, sites_per_launch: float):
@@ -73,6 +81,31 @@ def measured_traffic(precision: str, sites_per_launch: float):
         if rec and abs(rec.get("sites_per_launch", 0) - sites_per_launch) <= 0.5:
             return rec.get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT)
     return None, None
+
+
+def issue_bound(precision: str, sites_per_launch: float, avg_launch_s: float):
+    """The half-precision branch kernels are bound by the SIMDs' issue ports, not by the matrix cores: a matrix
+    instruction holds the port for its passes and a vector instruction for 4 clocks (tools/valu_rate_probe.hip;
+    tools/coexec_probe.hip shows the two do not overlap).  `peak` is the site rate of the W=51 kernel if no SIMD
+    ever waited: the instruction counts per launch come from the committed rocprofv3 --pmc pass
+    (SQ_INSTS_VALU, SQ_INSTS_MFMA, SQ_VALU_MFMA_BUSY_CYCLES), the launch time is the live HIP-event one."""
+    for path in ISSUE_FILES:
+        try:
+            with open(path) as f:
+                rec = json.load(f).get(precision)
+        except (OSError, ValueError):
+            continue
+        if not rec or "issue_cycles_per_site" not in rec or avg_launch_s <= 0:
+            continue
+        peak = N_SIMD * PEAK_CLOCK_GHZ * 1e9 / rec["issue_cycles_per_site"]
+        achieved = sites_per_launch / avg_launch_s
+        return {"bound": "valu", "kernel": KERNEL_NAME[precision], "achieved": achieved, "peak": peak,
+                "unit": "sites/s", "frac": achieved / peak,
+                "issue_cycles_per_site": rec["issue_cycles_per_site"],
+                "valu_insts_per_site": rec["valu_insts_per_site"], "mfma_insts_per_site": rec["mfma_insts_per_site"],
+                "mfma_cycles_per_inst": rec["mfma_cycles_per_inst"], "valu_cycles_per_inst": 4,
+                "simds": N_SIMD, "clock_ghz": PEAK_CLOCK_GHZ, "source": os.path.relpath(path, ROOT)}
+    return None
 
 
 # ------------------------------------------------------------------------------------ ranks
@@ -278,13 +311,38 @@ def measure_train(R: Ranks, batch: int, steps: int, warmup: int) -> dict:
             backend.trainer.apply(5e-4, 1e-4, 1.0, 1.0 / world, st)
 
     elapsed = R.timed(step, steps, warmup)
+    # one extra step with the per-kernel clocks armed (branches one after another on one stream)
+    backend.trainer.profile_begin()
+    step(steps + warmup)
+    kernel_ms = backend.trainer.profile_end()
+    R.barrier()
     w = backend.trainer.get_weights()
     assert np.isfinite(w).all()
     backend.close()
     value = world * batch * steps / elapsed
     tf = value / world * 3 * FLOPS_PER_SITE / 1e12
+    # dominant kernel: both TransformerBlocks + pooling backward of the W=51 branch, one launch per step
+    bwd_s = kernel_ms["tb_bwd51"] * 1e-3
+    bwd_tf = batch * 2 * TB_FWD_FLOPS[51] / bwd_s / 1e12 if bwd_s > 0 else 0.0
+    traffic, traffic_file = None, None
+    for path in TRAIN_TRAFFIC_FILES:
+        try:
+            with open(path) as f:
+                rec = json.load(f).get(f"batch{batch}")
+        except (OSError, ValueError):
+            continue
+        if rec:
+            traffic, traffic_file = rec.get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT)
+            break
+    roofline = {"bound": "mfma", "kernel": "tb_bwd_kernel<51>", "achieved": bwd_tf, "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": bwd_tf / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                "traffic_source": f"{traffic_file} (offline rocprofv3 --pmc passes of bench.py --train)" if traffic_file else None,
+                "avg_launch_ms": kernel_ms["tb_bwd51"], "sites_per_launch": batch,
+                "flops_per_site": 2 * TB_FWD_FLOPS[51]}
     return {"batch_per_gpu": batch, "steps": steps, "ms_per_step": elapsed / steps * 1e3, "sites_per_s": value,
-            "tflops_per_gpu": tf, "frac_of_f32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS}
+            "tflops_per_gpu": tf, "frac_of_f32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS, "roofline": roofline,
+            "kernel_ms_serial_step": {k: round(v, 4) for k, v in kernel_ms.items()},
+            "kernel_ms_serial_total": round(sum(kernel_ms.values()), 4)}
 
 
 def train_main(args, R: Ranks) -> None:
@@ -297,11 +355,11 @@ def train_main(args, R: Ranks) -> None:
             "data": "synthetic imbalanced sites (4.2% positive), seeded synthetic weights",
             "config": {"workload": "config 5: main.py-style training step", "batch_per_gpu": args.batch,
                        "parallelism": f"dp{R.world} (one flat 6.6 MB fp32 gradient all-reduce per step)"},
-            "roofline": {"bound": "mfma", "kernel": "whole step (forward + backward + AdamW)",
-                         "achieved": m["tflops_per_gpu"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": m["frac_of_f32_mfma_peak"], "traffic": None,
-                         "flops_per_site": 3 * FLOPS_PER_SITE},
-            "whole_path": {"tflops": m["tflops_per_gpu"]}}))
+            "roofline": m["roofline"],
+            "whole_path": {"tflops": m["tflops_per_gpu"], "frac_of_f32_mfma_peak": m["frac_of_f32_mfma_peak"],
+                           "flops_per_site": 3 * FLOPS_PER_SITE},
+            "kernel_ms_serial_step": m["kernel_ms_serial_step"],
+            "kernel_ms_serial_total": m["kernel_ms_serial_total"]}))
     R.finish()
 
 
@@ -582,6 +640,9 @@ def main() -> None:
             v_tf = n * FLOPS_BRANCH[51] / (v_ms * 1e-3) / 1e12 if v_ms > 0 else 0.0
             variants[mode] = {"sites_per_s_one_gpu": n / dt, "branch51_avg_launch_ms": v_ms / max(v_launches, 1),
                               "branch51_tflops_algorithmic": v_tf, "branch51_frac_of_mfma_peak": v_tf / PEAK_MFMA[mode]}
+            ib = issue_bound(mode, n / max(v_launches, 1), v_ms * 1e-3 / max(v_launches, 1))
+            if ib:
+                variants[mode]["roofline"] = ib
         sc.set_precision(args.precision)
     R.barrier()
 
@@ -629,6 +690,11 @@ def main() -> None:
             "kernel_ms_per_step": {k: round(v[0], 3) for k, v in prof.items()},
             "kernel_ms_total": round(total_kernel_ms, 3),
         }
+        if args.precision != "f32":
+            ib = issue_bound(args.precision, sites_per_launch, avg_s)
+            if ib:       # the half-precision kernels are issue-bound: the matrix-peak fraction stays beside it
+                line["roofline_mfma"] = line["roofline"]
+                line["roofline"] = dict(ib, traffic=traffic, avg_launch_ms=avg_s * 1e3, sites_per_launch=sites_per_launch)
         if variants:
             line["variants"] = variants
         line.update(extras)

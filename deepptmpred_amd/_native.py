@@ -33,6 +33,7 @@ EXPORTS = (
     "dptm_trainer_grad_buffer", "dptm_trainer_param_floats", "dptm_trainer_apply",
     "dptm_trainer_get_weights", "dptm_trainer_get_grads", "dptm_trainer_get_proba",
     "dptm_trainer_get_optimizer_state", "dptm_trainer_set_optimizer_state",
+    "dptm_trainer_profile_begin", "dptm_trainer_profile_end",
     "dptm_trainer_last_error", "dptm_trainer_set_allreduce", "dptm_sasa", "dptm_sasa_last_error",
 )
 
@@ -176,6 +177,10 @@ def load_library() -> C.CDLL:
     lib.dptm_trainer_get_optimizer_state.argtypes = [vp, f32p, f32p, C.POINTER(i64)]
     lib.dptm_trainer_set_optimizer_state.restype = C.c_int
     lib.dptm_trainer_set_optimizer_state.argtypes = [vp, f32p, f32p, i64]
+    lib.dptm_trainer_profile_begin.restype = C.c_int
+    lib.dptm_trainer_profile_begin.argtypes = [vp]
+    lib.dptm_trainer_profile_end.restype = C.c_int
+    lib.dptm_trainer_profile_end.argtypes = [vp, f32p]
     lib.dptm_trainer_set_allreduce.restype = C.c_int
     lib.dptm_trainer_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
     lib.dptm_trainer_last_error.restype = C.c_char_p
@@ -475,6 +480,18 @@ class Trainer:
             raise ValueError("optimizer moments must hold one float per weight of the canonical blob")
         _check_t(self._lib, self._lib.dptm_trainer_set_optimizer_state(self._h, _ptr(m), _ptr(v), int(step)),
                  "dptm_trainer_set_optimizer_state")
+
+    PROFILE_KERNELS = ("conv_a_fwd", "conv_b_fwd", "tb_fwd", "tb_bwd", "conv_b_bwd", "conv_a_bwd")
+
+    def profile_begin(self) -> None:
+        """Arms the per-kernel clocks: until profile_end() the sequence branches run one after another on one stream."""
+        _check_t(self._lib, self._lib.dptm_trainer_profile_begin(self._h), "dptm_trainer_profile_begin")
+
+    def profile_end(self) -> dict:
+        """{"tb_bwd51": ms, ...} for the sequence-branch launches of the last step."""
+        ms = np.zeros(18, dtype=np.float32)
+        _check_t(self._lib, self._lib.dptm_trainer_profile_end(self._h, _ptr(ms)), "dptm_trainer_profile_end")
+        return {f"{k}{w}": float(ms[b * 6 + i]) for b, w in enumerate((21, 33, 51)) for i, k in enumerate(self.PROFILE_KERNELS)}
 
     def get_proba(self, n: int) -> np.ndarray:
         out = np.empty((n, 2), dtype=np.float32)

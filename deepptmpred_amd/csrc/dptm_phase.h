@@ -9,10 +9,17 @@ namespace dptm { static __device__ unsigned long long g_phase_cycles[32]; }   //
 #define PH_MARK(id) { const unsigned long long ph_t1 = __builtin_amdgcn_s_memtime(); ph_acc[id] += ph_t1 - ph_t0; ph_t0 = ph_t1; }
 #define PH_FLUSH if ((threadIdx.x & 63) == 0) { for (int ph_i = 0; ph_i < 12; ++ph_i) atomicAdd(&dptm::g_phase_cycles[ph_i], ph_acc[ph_i]); \
     atomicAdd(&dptm::g_phase_cycles[16 + ((threadIdx.x >> 6) & 7)], ph_acc[2] + ph_acc[4]); atomicAdd(&dptm::g_phase_cycles[24 + ((threadIdx.x >> 6) & 7)], ph_acc[5]); }
+// for device functions that mark phases of the kernel they are inlined into
+#define PH_PARAMS , unsigned long long& ph_t0, unsigned long long* ph_acc
+#define PH_ARGS , ph_t0, ph_acc
+#define PH_WAIT_VM __builtin_amdgcn_s_waitcnt(0x0F70);
 #else
 #define PH_DECL
 #define PH_MARK(id)
 #define PH_FLUSH
+#define PH_PARAMS
+#define PH_ARGS
+#define PH_WAIT_VM
 #endif
 
 #ifdef DPTM_PHASE_TIMING

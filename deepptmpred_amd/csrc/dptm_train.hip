@@ -165,6 +165,11 @@ struct dptm_trainer {
     int64_t n_local = 1, n_global = 1;    // sites of the current call here / over all replicas
     bool serial = false;                  // DPTM_TRAIN_SERIAL=1: branches on the caller's stream too (per-kernel profiling)
     bool use_graph = false;               // opt-in (DPTM_TRAIN_GRAPH=1): replay measures slower than eager multi-stream issue
+    // per-kernel clocks of one step (dptm_trainer_profile_begin / _end): event pairs around the six launches of
+    // every sequence branch, slot = branch * 6 + {conv_a_fwd, conv_b_fwd, tb_fwd, tb_bwd, conv_b_bwd, conv_a_bwd}
+    bool prof_on = false, prof_serial_before = false;
+    hipEvent_t prof_ev[DPTM_TRAIN_PROFILE_SLOTS][2] = {};
+    bool prof_used[DPTM_TRAIN_PROFILE_SLOTS] = {};
 };
 
 namespace {
@@ -203,6 +208,7 @@ int alloc_acts(dptm_trainer* t) {
           need(t->t1a, B * 512) && need(t->t1y, B * 512) && need(t->t1mi, 1024) && need(t->t1z, B * 512) &&
           need(t->t2a, B * 256) && need(t->t2y, B * 256) && need(t->t2mi, 512) && need(t->t2z, B * 256) &&
           need(t->proba, B * 2) && need(t->d_loss, 64) && need(t->bn_slots, 2 * kBnLayers * 1024);
+    ok = ok && t->bn_slots == t->d_loss + 64;      // one fill clears both every step
     for (int b = 0; b < 4; ++b) {
         dptm_trainer::Scratch& s = t->sc[b];
         ok &= need(s.bnsums_all, 1024);
@@ -303,6 +309,22 @@ GemmTnArgs gt(const float* x, int64_t ldx, int xoff, const float* dy, int64_t ld
 
 struct Rates { float embed, conv, tb, dense; };
 
+// While a profile is armed, brackets one launch with an event pair on the launch's own stream.
+struct ProfScope {
+    dptm_trainer* t;
+    hipStream_t st;
+    int slot;
+    ProfScope(const Ctx& c, int slot_) : t(c.t), st(c.st), slot(slot_) {
+        if (t->prof_on) (void)hipEventRecord(t->prof_ev[slot][0], st);
+    }
+    ~ProfScope() {
+        if (t->prof_on) {
+            (void)hipEventRecord(t->prof_ev[slot][1], st);
+            t->prof_used[slot] = true;
+        }
+    }
+};
+
 // per-branch arguments shared by the four convolution-block kernels
 ConvArgs conv_args(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigned* seed, const Rates& rt, const TileCfg& tc) {
     dptm_trainer* t = c.t;
@@ -358,9 +380,15 @@ int branch_fwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
     const TileCfg tc = t_tile_cfg(B, wl);
     const ConvArgs cf = conv_args(c, b, tok, B, seed, rt, tc);
     int rc;
-    T_TRY(t_conv_a_fwd(cf, wl, tc.NW, c.st));
+    {
+        ProfScope ps(c, b * 6 + 0);
+        T_TRY(t_conv_a_fwd(cf, wl, tc.NW, c.st));
+    }
     if ((rc = replica_sum(c, cf.stats1, 128))) return rc;
-    T_TRY(t_conv_b_fwd(cf, wl, tc.NW, c.st));
+    {
+        ProfScope ps(c, b * 6 + 1);
+        T_TRY(t_conv_b_fwd(cf, wl, tc.NW, c.st));
+    }
     if ((rc = replica_sum(c, cf.stats2, 128))) return rc;
     {
         // BN2 + shortcut add, both TransformerBlocks and the attention pooling (model.py:138-141, 172-182)
@@ -381,6 +409,7 @@ int branch_fwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
         f.stream_base = (unsigned)(b * 8 + 2);
         f.thr = dropout_threshold(rt.tb);
         f.scale = rt.tb > 0.f ? 1.0f / (1.0f - rt.tb) : 1.0f;
+        ProfScope ps(c, b * 6 + 2);
         T_TRY(t_tb_fwd(f, wl, tc.NW, c.st));
     }
     return DPTM_OK;
@@ -428,6 +457,7 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
         }
         g.poolw = c.g(p.poolk);
         g.poolb = c.g(p.poolb);
+        ProfScope ps(c, b * 6 + 3);
         T_TRY(t_tb_bwd(f, g, wl, tc.NW, c.st));
     }
     const ConvGrads cg{c.g(p.emb), c.g(p.pos), c.g(p.sck), c.g(p.scb), c.g(p.c3ak), c.g(p.c3ab), c.g(p.c3bk), c.g(p.c3bb)};
@@ -436,12 +466,18 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
         T_TRY(hipMemcpyAsync(c.s->bnsums_all + 128, cf.bb2.own, 128 * sizeof(float), hipMemcpyDeviceToDevice, c.st));
         if ((rc = replica_sum(c, c.s->bnsums_all + 128, 128))) return rc;
     }
-    T_TRY(t_conv_b_bwd(cf, cg, wl, tc.NW, c.st));
+    {
+        ProfScope ps(c, b * 6 + 4);
+        T_TRY(t_conv_b_bwd(cf, cg, wl, tc.NW, c.st));
+    }
     if (t->ar_fn) {
         T_TRY(hipMemcpyAsync(c.s->bnsums_all, cf.bb1.own, 128 * sizeof(float), hipMemcpyDeviceToDevice, c.st));
         if ((rc = replica_sum(c, c.s->bnsums_all, 128))) return rc;
     }
-    T_TRY(t_conv_a_bwd(cf, cg, wl, tc.NW, c.st));
+    {
+        ProfScope ps(c, b * 6 + 5);
+        T_TRY(t_conv_a_bwd(cf, cg, wl, tc.NW, c.st));
+    }
     return DPTM_OK;
 }
 
@@ -480,6 +516,8 @@ void dptm_trainer_destroy(dptm_trainer* t) {
         if (t->aux[b]) (void)hipStreamDestroy(t->aux[b]);
     for (int ph = 0; ph < 2; ++ph) {
         if (t->ev_caller[ph]) (void)hipEventDestroy(t->ev_caller[ph]);
+        for (int k = 0; k < DPTM_TRAIN_PROFILE_SLOTS; ++k)
+            if (t->prof_ev[k][ph]) (void)hipEventDestroy(t->prof_ev[k][ph]);
         if (t->ev_fork[ph]) (void)hipEventDestroy(t->ev_fork[ph]);
         for (int b = 0; b < 3; ++b)
             if (t->ev_join[ph][b]) (void)hipEventDestroy(t->ev_join[ph][b]);
@@ -509,6 +547,8 @@ int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spe
     t->max_batch = max_batch;
     auto bail = [&](int code, const char* msg) { return tfail(code, msg); };   // `owner` frees the half-built trainer
     if (hipSetDevice(device) != hipSuccess) return bail(DPTM_EINVAL, "dptm_trainer_create: no such device");
+    // four streams created back to back: the runtime hands out its hardware queues in turn, so the four land on
+    // four different queues (streams of the caller's that share one of them are idle while a step runs)
     if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) return bail(DPTM_EHIP, "hipStreamCreate failed");
     for (int b = 0; b < 3; ++b)
         if (hipStreamCreateWithFlags(&t->aux[b], hipStreamNonBlocking) != hipSuccess) return bail(DPTM_EHIP, "hipStreamCreate failed");
@@ -649,19 +689,21 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
     int rc;
     T_TRY(hipMemsetAsync(t->G, 0, (size_t)pm.total * sizeof(float), st));
     T_TRY(t_pack(t->pack_jobs, t->n_pack_jobs, st));          // weight images of this step's weights
-    T_TRY(hipMemsetAsync(t->d_loss, 0, 64 * sizeof(float), st));
-    T_TRY(hipMemsetAsync(t->bn_slots, 0, (size_t)2 * kBnLayers * 1024 * sizeof(float), st));
+    // loss accumulator and BatchNorm column sums: allocated back to back (alloc_acts), cleared by one fill
+    T_TRY(hipMemsetAsync(t->d_loss, 0, (size_t)(64 + 2 * kBnLayers * 1024) * sizeof(float), st));
     // Small batches without a statistics all-reduce take the per-column kernels of dptm_train_site.hip: one launch per
     // layer and direction instead of a product and half a dozen element-wise passes each.
     const bool small = B <= kSiteMaxRows && !t->ar_fn &&
                        ((reinterpret_cast<uintptr_t>(strct) | reinterpret_cast<uintptr_t>(esm)) & 15) == 0;
-    // ---------------- forward.  Three lanes of work: the W=21 and W=33 branches on side streams, the W=51 branch (the
-    // longest) on the caller's stream `st`; the structure / ESM layers of a small batch follow the W=21 branch on its
-    // stream `ss`.  (The hardware has few queues: more streams than this end up sharing one and serialise.)
+    // ---------------- forward.  Four lanes of work: the W=21 and W=33 branches on side streams, the W=51 branch (the
+    // longest) on the step's main stream `st`, the structure / ESM layers of a small batch on a third side stream `ss`.
+    // (A process has four hardware queues: a fifth concurrent stream would share one and serialise behind it.)
     hipStream_t bstream[3] = {t->serial ? st : t->aux[0], t->serial ? st : t->aux[1], st};
-    hipStream_t ss = small ? bstream[0] : st;
+    hipStream_t ss = small && !t->serial ? t->aux[2] : st;
+    hipStream_t side[3] = {bstream[0], bstream[1], ss};
+    // the longest branch first: its launches are then the first the host hands to the device
     auto branches = [&](bool forward, int first, int last) -> int {
-        for (int b = first; b <= last; ++b) {
+        for (int b = last; b >= first; --b) {
             Ctx cb{t, bstream[b], t->W, t->G, &t->sc[b]};
             const int r = forward ? branch_fwd(cb, b, tok[b], B, seed, rt) : branch_bwd(cb, b, tok[b], B, seed, rt);
             if (r) return r;
@@ -670,21 +712,21 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
     };
     auto fork = [&](int phase) -> int {
         T_TRY(hipEventRecord(t->ev_fork[phase], st));
-        for (int b = 0; b < 2; ++b)
-            if (bstream[b] != st) T_TRY(hipStreamWaitEvent(bstream[b], t->ev_fork[phase], 0));
+        for (int b = 0; b < 3; ++b)
+            if (side[b] != st) T_TRY(hipStreamWaitEvent(side[b], t->ev_fork[phase], 0));
         return DPTM_OK;
     };
     auto join = [&](int phase) -> int {
-        for (int b = 0; b < 2; ++b)
-            if (bstream[b] != st) {
-                T_TRY(hipEventRecord(t->ev_join[phase][b], bstream[b]));
+        for (int b = 0; b < 3; ++b)
+            if (side[b] != st) {
+                T_TRY(hipEventRecord(t->ev_join[phase][b], side[b]));
                 T_TRY(hipStreamWaitEvent(st, t->ev_join[phase][b], 0));
             }
         return DPTM_OK;
     };
     if ((rc = fork(0))) return rc;
-    if ((rc = branches(true, 0, 1))) return rc;
     if (small) {
+        if ((rc = branches(true, 2, 2))) return rc;       // the longest lane first
         const float sc = rt.dense > 0.f ? 1.0f / (1.0f - rt.dense) : 1.0f;
         const unsigned thr = dropout_threshold(rt.dense);
         auto dropd = [&](int stream, int cols, int col0) { return SiteDrop{(unsigned)stream, thr, sc, cols, col0}; };
@@ -706,7 +748,7 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
         T_TRY(fwd(strct, 8, 8, none, pm.strct, 128, t->sa, true, t->smi, dropd(24 + 0, 128, 0), t->concat, kConcat, 192));
         T_TRY(fwd(esm, kEsm, kEsm, none, pm.esm1, 512, t->ea, true, t->emi, dropd(24 + 1, 512, 0), t->e1, 512, 0));
         T_TRY(fwd(t->e1, 512, 512, none, pm.esm2, 256, t->e2a, false, nullptr, none, t->concat, kConcat, 320));
-        if ((rc = branches(true, 2, 2))) return rc;
+        if ((rc = branches(true, 0, 1))) return rc;
         if ((rc = join(0))) return rc;              // pooled branch outputs, structure and ESM columns are in concat
         ls = st;
         // trunk (model.py:198-205); the dropout in front of it is applied where the concatenation is read
@@ -738,8 +780,8 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
         T_TRY(bwd(nullptr, t->d512b, 512, &pm.t1, 0, dropd(24 + 2, kConcat, 0), t->dconcat, none, nullptr, false, nullptr, nullptr, nullptr,
                   nullptr, 0, 0, none, 192));
         if ((rc = fork(1))) return rc;
-        if ((rc = branches(false, 0, 1))) return rc;
-        // ESM and structure layers behind the W=21 branch, side by side with the other two
+        if ((rc = branches(false, 2, 2))) return rc;      // the longest lane first
+        // ESM and structure layers on a stream of their own, side by side with the three branches
         ls = ss;
         T_TRY(bwd(nullptr, t->d512b, 512, &pm.t1, 320, dropd(24 + 2, kConcat, 320), nullptr, none, &pm.esm2, false, nullptr, t->e2a, t->d256a,
                   t->e1, 512, 512, none, 256));
@@ -747,8 +789,9 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
                   t->sa, t->d128, strct, 8, 8, none, 128));
         T_TRY(bwd(nullptr, t->d256a, 256, &pm.esm2, 0, none, nullptr, dropd(24 + 1, 512, 0), &pm.esm1, true, t->emi, t->ea, t->d512a, esm, kEsm,
                   kEsm, none, 512));
-        if ((rc = branches(false, 2, 2))) return rc;
+        if ((rc = branches(false, 0, 1))) return rc;
     } else {
+        if ((rc = branches(true, 0, 1))) return rc;
         // struct branch (model.py:187-189)
         auto dense_swish = [&](GemmArgs g, float* act, int64_t lda) {     // pre-activation to g.out, swish of it to act
             g.act_out = act; g.lda = lda;
@@ -901,6 +944,44 @@ int dptm_trainer_forward_backward(dptm_trainer* t, const uint8_t* tok21, const u
     return DPTM_OK;
 } catch (...) {
     return on_texception("dptm_trainer_forward_backward");
+}
+
+// Arms the per-kernel clocks: until dptm_trainer_profile_end the step's branches run one after another on one
+// stream (so that a duration is the kernel's own and not its share of a GPU it co-runs on) and every
+// sequence-branch launch is bracketed by an event pair on that stream.
+int dptm_trainer_profile_begin(dptm_trainer* t) try {
+    if (!t) return tfail(DPTM_EINVAL, "dptm_trainer_profile_begin: NULL trainer");
+    if (t->use_graph) return tfail(DPTM_EINVAL, "dptm_trainer_profile_begin: not available with graph replay (DPTM_TRAIN_GRAPH)");
+    T_TRY(hipSetDevice(t->device));
+    for (int k = 0; k < DPTM_TRAIN_PROFILE_SLOTS; ++k) {
+        for (int e = 0; e < 2; ++e)
+            if (!t->prof_ev[k][e]) T_TRY(hipEventCreate(&t->prof_ev[k][e]));
+        t->prof_used[k] = false;
+    }
+    if (!t->prof_on) t->prof_serial_before = t->serial;
+    t->serial = true;
+    t->prof_on = true;
+    return DPTM_OK;
+} catch (...) {
+    return on_texception("dptm_trainer_profile_begin");
+}
+
+// Waits for the device and writes the milliseconds of the LAST step's launches (0 for a slot the step did not
+// use: batches of at most 128 sites take other kernels for the per-site layers, never for the branches).
+int dptm_trainer_profile_end(dptm_trainer* t, float* ms_out) try {
+    if (!t || !ms_out) return tfail(DPTM_EINVAL, "dptm_trainer_profile_end: NULL argument");
+    if (!t->prof_on) return tfail(DPTM_EINVAL, "dptm_trainer_profile_end: no profile armed");
+    T_TRY(hipSetDevice(t->device));
+    T_TRY(hipDeviceSynchronize());
+    t->prof_on = false;
+    t->serial = t->prof_serial_before;
+    for (int k = 0; k < DPTM_TRAIN_PROFILE_SLOTS; ++k) {
+        ms_out[k] = 0.f;
+        if (t->prof_used[k]) T_TRY(hipEventElapsedTime(&ms_out[k], t->prof_ev[k][0], t->prof_ev[k][1]));
+    }
+    return DPTM_OK;
+} catch (...) {
+    return on_texception("dptm_trainer_profile_end");
 }
 
 int dptm_trainer_set_allreduce(dptm_trainer* t, dptm_allreduce_fn fn, void* user) try {

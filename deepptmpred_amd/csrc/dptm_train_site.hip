@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dptm_mfma.h"
+#include "dptm_phase.h"
 #include "dptm_train_device.h"
 #include "dptm_train_kernels.h"
 
@@ -35,30 +36,41 @@ __device__ __forceinline__ float drop(float v, const SiteDrop& d, unsigned seed,
 //   D[m = column][n = row] += sum_k A[m][k] B[k][n]
 // colmat(col, k) / rowmat(row, k) return the four operand values at k .. k+3.  The contraction index is walked in groups
 // of 8: the lower half-wave takes k = 8q .. 8q+3, the upper one 8q+4 .. 8q+7 (any pairing of the two halves is a valid
-// MFMA step), so that operands that are contiguous along k arrive as 16-byte loads; kGroupsInFlight groups are
-// requested before the first product of a batch.  Every wavefront then adds its tiles to the LDS tile [row][column].
-constexpr int kGroupsInFlight = 8;
+// MFMA step), so that operands that are contiguous along k arrive as 16-byte loads; groups_in_flight() groups are
+// requested before the first product of a batch.  The wavefronts' partial tiles are then summed into the LDS tile
+// [row][column] (every thread of the workgroup must call this: barriers inside; `part` holds 4096 floats).
+template <int RT> constexpr int groups_in_flight() { return RT <= 2 ? 12 : 4; }
 
-template <int RT, typename FA, typename FB>
-__device__ __forceinline__ void split_k_product(int K, FA colmat, FB rowmat, float* tile, int lane, int wave, int nwaves) {
+template <int RT, typename FA, typename FB, typename FM>
+__device__ __forceinline__ void split_k_product(int K, FA colmat, FB rowmat, FM rowmask, float* tile, float* part, int lane, int wave, int nwaves PH_PARAMS) {
     const int hh = lane >> 5, i = lane & 31;
     f32x16 acc[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int rg = 0; rg < 16; ++rg) acc[rt][rg] = 0.f;
+    constexpr int kGroupsInFlight = groups_in_flight<RT>();
     const int groups = K >> 3;
     const int per = (groups + nwaves - 1) / nwaves;
     const int g0 = wave * per, g1 = min(groups, g0 + per);
     for (int gb = g0; gb < g1; gb += kGroupsInFlight) {
         f32x4 a[kGroupsInFlight], b[kGroupsInFlight][RT];
+        // every load of the batch is requested before anything waits for one: masks (which need the values) come after
+#pragma unroll
+        for (int v = 0; v < kGroupsInFlight; ++v) {
+            const int k = 8 * min(gb + v, g1 - 1) + 4 * hh;
+            a[v] = colmat(i, k);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) b[v][rt] = rowmat(32 * rt + i, k);
+        }
+        PH_WAIT_VM
+        PH_MARK(1)   // operand loads
 #pragma unroll
         for (int v = 0; v < kGroupsInFlight; ++v) {
             const int k = 8 * (gb + v) + 4 * hh;
-            const bool ok = gb + v < g1;
-            a[v] = ok ? colmat(i, k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (gb + v >= g1) a[v] = f32x4{0.f, 0.f, 0.f, 0.f};      // a group past the end was read again: drop it
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) b[v][rt] = ok ? rowmat(32 * rt + i, k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int rt = 0; rt < RT; ++rt) rowmask(b[v][rt], 32 * rt + i, k);
         }
 #pragma unroll
         for (int v = 0; v < kGroupsInFlight; ++v)
@@ -66,24 +78,40 @@ __device__ __forceinline__ void split_k_product(int K, FA colmat, FB rowmat, flo
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) mfma(acc[rt], a[v][e], b[v][rt][e]);
+        PH_MARK(4)   // masks and products
     }
+    // The eight partial tiles meet in LDS, one 32-row block at a time: the upper four wavefronts hand theirs to the
+    // lower four, these add their own and hand the sums back, then all threads add the four sums into the tile.
+    // (Plain stores and loads: LDS float atomics from eight wavefronts on the same addresses run many times slower.)
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int rt = 0; rt < RT; ++rt) {
+        float* mine = part + (wave & 3) * 1024 + lane;
+        if (wave >= 4) {
 #pragma unroll
-        for (int rg = 0; rg < 16; ++rg) {
-            const int m = (rg & 3) + 8 * (rg >> 2) + 4 * hh;
-            atomicAdd(&tile[(32 * rt + i) * kTilePad + m], acc[rt][rg]);
+            for (int rg = 0; rg < 16; ++rg) mine[rg * 64] = acc[rt][rg];
         }
+        __syncthreads();
+        if (wave < 4) {
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) mine[rg * 64] += acc[rt][rg];
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < 1024; o += 512) {
+            const int rg = o >> 6, ln = o & 63;
+            const int m = (rg & 3) + 8 * (rg >> 2) + 4 * (ln >> 5);
+            tile[(32 * rt + (ln & 31)) * kTilePad + m] = (part[o] + part[1024 + o]) + (part[2048 + o] + part[3072 + o]);
+        }
+        __syncthreads();
+    }
+    PH_MARK(5)   // LDS reduction
 }
 
-// four consecutive elements of a row with the row's dropout mask
-__device__ __forceinline__ f32x4 load4_drop(const float* row, int k, const SiteDrop& d, unsigned seed, int64_t r) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(row + k);
+// dropout mask of four consecutive elements k .. k+3 of row r
+__device__ __forceinline__ void mask4(f32x4& v, int k, const SiteDrop& d, unsigned seed, int64_t r) {
     if (d.thr != 0u) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = drop(v[e], d, seed, r, k + e);
     }
-    return v;
 }
 
 // sums over the batch rows of f(r, c) for the 32 columns of the tile, by all 512 threads: thread (c, g) walks rows
@@ -117,31 +145,44 @@ __device__ __forceinline__ void column_sums(int B, F f, float* red, float* out1,
 template <int RT>
 __global__ __launch_bounds__(512) void site_fwd_kernel(SiteFwdArgs p) {
     __shared__ float tile[RT * 32 * kTilePad];
-    __shared__ float red[1024];
+    __shared__ float part[4096];                   // partial tiles of the product; later the column-sum scratch
     __shared__ float cs1[32], cs2[32], csc[32], csh[32];
+    float* red = part;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * 32;
+    PH_DECL
     const unsigned seed = p.step[kStepSeed];
-    for (int o = tid; o < RT * 32 * kTilePad; o += 512) tile[o] = 0.f;
-    __syncthreads();
+    // per-column parameters of this thread's column (c = tid & 31 in every loop below): requested before the product
+    const int cc = tid & 31;
+    const float bias_c = p.bias[n0 + cc];
+    const float gamma_c = p.bn ? p.gamma[n0 + cc] : 1.f, beta_c = p.bn ? p.beta[n0 + cc] : 0.f;
+    PH_MARK(0)   // start-up
     split_k_product<RT>(
         p.K,
         [&](int c, int k) {
             const float* w = p.W + (int64_t)k * p.N + n0 + c;
             return f32x4{w[0], w[p.N], w[2 * (int64_t)p.N], w[3 * (int64_t)p.N]};
         },
-        [&](int r, int k) {
-            return r < p.B ? load4_drop(p.x + (int64_t)r * p.ldx, k, p.in_drop, seed, r) : f32x4{0.f, 0.f, 0.f, 0.f};
+        [&](int r, int k) {      // rows past the batch read the last row again and are zeroed by the mask step
+            return *reinterpret_cast<const f32x4*>(p.x + (int64_t)min(r, p.B - 1) * p.ldx + k);
         },
-        tile, lane, wave, 8);
+        [&](f32x4& v, int r, int k) {
+            if (r < p.B)
+                mask4(v, k, p.in_drop, seed, r);
+            else
+                v = f32x4{0.f, 0.f, 0.f, 0.f};
+        },
+        tile, part, lane, wave, 8 PH_ARGS);
     __syncthreads();
+    PH_MARK(2)   // wait for the other wavefronts
     for (int o = tid; o < p.B * 32; o += 512) {
         const int r = o >> 5, c = o & 31;
-        const float v = tile[r * kTilePad + c] + p.bias[n0 + c];
+        const float v = tile[r * kTilePad + c] + bias_c;
         p.a[(int64_t)r * p.N + n0 + c] = v;
         tile[r * kTilePad + c] = swishf(v);
     }
     __syncthreads();
+    PH_MARK(3)   // bias, pre-activation out, swish
     if (p.bn) {
         column_sums(p.B, [&](int r, int c, float& v1, float& v2) {
             const float y = tile[r * kTilePad + c];
@@ -157,9 +198,9 @@ __global__ __launch_bounds__(512) void site_fwd_kernel(SiteFwdArgs p) {
             p.mi[p.N + n0 + tid] = inv;
             p.batch_mean[n0 + tid] = mu;
             p.batch_var[n0 + tid] = var;
-            const float sc = inv * p.gamma[n0 + tid];
+            const float sc = inv * gamma_c;
             csc[tid] = sc;
-            csh[tid] = p.beta[n0 + tid] - mu * sc;
+            csh[tid] = beta_c - mu * sc;
         }
         __syncthreads();
     }
@@ -169,6 +210,8 @@ __global__ __launch_bounds__(512) void site_fwd_kernel(SiteFwdArgs p) {
         if (p.bn) z = fmaf(z, csc[c], csh[c]);
         p.out[(int64_t)r * p.ldo + p.col_off + n0 + c] = drop(z, p.out_drop, seed, r, n0 + c);
     }
+    PH_MARK(3)   // batch statistics, normalise, dropout, store
+    PH_FLUSH
 }
 
 // grid: N / 32 workgroups (N = columns of the layer, or of the plain gradient block when there is no layer), block 512
@@ -176,12 +219,17 @@ template <int RT>
 __global__ __launch_bounds__(512) void site_bwd_kernel(SiteBwdArgs p) {
     __shared__ float tile[RT * 32 * kTilePad];     // upstream gradient, then d(a)
     __shared__ float ta[RT * 32 * kTilePad];       // pre-activation a of my columns
-    __shared__ float red[1024];
+    __shared__ float part[4096];                   // partial tiles of the product; later the column-sum scratch
+    float* red = part;
     __shared__ float cs1[32], cs2[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, i = lane & 31;
     const int n0 = blockIdx.x * 32;
+    PH_DECL
     const unsigned seed = p.step[kStepSeed];
+    // per-column parameters of this thread's column (c = tid & 31 in every loop below): requested before the product
+    const int cc = tid & 31;
+    const float mu_c = p.bn ? p.mi[n0 + cc] : 0.f, inv_c = p.bn ? p.mi[p.N + n0 + cc] : 1.f, gamma_c = p.bn ? p.gamma[n0 + cc] : 1.f;
     if (p.a) {
         for (int o = tid; o < p.B * 32; o += 512) {
             const int r = o >> 5, c = o & 31;
@@ -195,17 +243,18 @@ __global__ __launch_bounds__(512) void site_bwd_kernel(SiteBwdArgs p) {
             tile[r * kTilePad + c] = r < p.B ? p.dzd[(int64_t)r * p.ld_dzd + n0 + c] : 0.f;
         }
     } else {
-        for (int o = tid; o < RT * 32 * kTilePad; o += 512) tile[o] = 0.f;
-        __syncthreads();
         const int64_t wrow = p.next_row_off + n0;
         split_k_product<RT>(
             p.Nn, [&](int c, int k) { return *reinterpret_cast<const f32x4*>(p.W_next + (wrow + c) * p.Nn + k); },
-            [&](int r, int k) {
-                return r < p.B ? *reinterpret_cast<const f32x4*>(p.da_next + (int64_t)r * p.Nn + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+            [&](int r, int k) { return *reinterpret_cast<const f32x4*>(p.da_next + (int64_t)min(r, p.B - 1) * p.Nn + k); },
+            [&](f32x4& v, int r, int k) {
+                if (r >= p.B) v = f32x4{0.f, 0.f, 0.f, 0.f};
             },
-            tile, lane, wave, 8);
+            tile, part, lane, wave, 8 PH_ARGS);
     }
+    PH_MARK(6)   // upstream gradient read
     __syncthreads();
+    PH_MARK(2)
     for (int o = tid; o < p.B * 32; o += 512) {
         const int r = o >> 5, c = o & 31;
         float g = drop(tile[r * kTilePad + c], p.mid_drop, seed, r, n0 + c);
@@ -213,13 +262,18 @@ __global__ __launch_bounds__(512) void site_bwd_kernel(SiteBwdArgs p) {
         g = drop(g, p.out_drop, seed, r, n0 + c);
         tile[r * kTilePad + c] = g;
     }
-    if (!p.a) return;      // a plain gradient block: nothing below it in this launch
+    if (!p.a) {            // a plain gradient block: nothing below it in this launch
+        PH_MARK(7)
+        PH_FLUSH
+        return;
+    }
     __syncthreads();
+    PH_MARK(7)   // dropout masks, gradient out
     // ---- BatchNorm backward (column sums over the batch are local to the workgroup), swish backward
     if (p.bn) {
         column_sums(p.B, [&](int r, int c, float& v1, float& v2) {
             const float dz = tile[r * kTilePad + c];
-            const float xh = (swishf(ta[r * kTilePad + c]) - p.mi[n0 + c]) * p.mi[p.N + n0 + c];
+            const float xh = (swishf(ta[r * kTilePad + c]) - mu_c) * inv_c;
             v1 = dz;
             v2 = dz * xh;
         }, red, cs1, cs2);
@@ -228,6 +282,7 @@ __global__ __launch_bounds__(512) void site_bwd_kernel(SiteBwdArgs p) {
             p.dbeta[n0 + tid] += cs1[tid];
         }
     }
+    PH_MARK(8)   // BatchNorm backward sums
     const float inv_b = 1.0f / (float)p.B;
     for (int o = tid; o < p.B * 32; o += 512) {
         const int r = o >> 5, c = o & 31;
@@ -235,15 +290,15 @@ __global__ __launch_bounds__(512) void site_bwd_kernel(SiteBwdArgs p) {
         const float sg = fast_rcp(1.0f + __expf(-v));
         float dy = tile[r * kTilePad + c];
         if (p.bn) {
-            const float mu = p.mi[n0 + c], inv = p.mi[p.N + n0 + c];
-            const float xh = (v * sg - mu) * inv;
-            dy = p.gamma[n0 + c] * inv * (dy - cs1[c] * inv_b - xh * cs2[c] * inv_b);
+            const float xh = (v * sg - mu_c) * inv_c;
+            dy = gamma_c * inv_c * (dy - cs1[c] * inv_b - xh * cs2[c] * inv_b);
         }
         const float da = dy * (sg * (1.0f + v * (1.0f - sg)));
         p.da[(int64_t)r * p.N + n0 + c] = da;
         tile[r * kTilePad + c] = da;
     }
     __syncthreads();
+    PH_MARK(9)   // d(a)
     {
         float* db1 = cs1;
         column_sums(p.B, [&](int r, int c, float& v1, float& v2) {
@@ -254,31 +309,54 @@ __global__ __launch_bounds__(512) void site_bwd_kernel(SiteBwdArgs p) {
     }
     // ---- my 32 columns of dW = x^T d(a): 32-row blocks of dW over the wavefronts, contraction over the batch rows
     // (rows 8q + 4hh + e meet in step 4q + e; all loads of a block are requested before its first product)
+    PH_MARK(10)  // bias gradient
+    // Several blocks per pass, so that their loads are all in flight; this kernel is the only writer of its dW columns.
+    constexpr int U = RT <= 1 ? 4 : RT == 2 ? 3 : 1;
     const int mt = (p.K + 31) / 32;
-    for (int t = wave; t < mt; t += 8) {
-        const int k = 32 * t + i;
-        f32x4 a[RT * 4], b[RT * 4];
+    for (int t = wave; t < mt; t += 8 * U) {
+        f32x4 a[U][RT * 4], b[RT * 4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kc = min(32 * (t + 8 * u) + i, p.K - 1);
+#pragma unroll
+            for (int q = 0; q < RT * 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 8 * q + 4 * hh + e;
+                    a[u][q][e] = p.x[(int64_t)min(r, p.B - 1) * p.ldx + kc];      // all loads first, masks afterwards
+                }
+        }
 #pragma unroll
         for (int q = 0; q < RT * 4; ++q)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 8 * q + 4 * hh + e;
-                a[q][e] = (r < p.B && k < p.K) ? drop(p.x[(int64_t)r * p.ldx + k], p.in_drop, seed, r, k) : 0.f;
-                b[q][e] = tile[r * kTilePad + i];    // rows >= B hold zeros (never written after the load phase)
+            for (int e = 0; e < 4; ++e) b[q][e] = tile[(8 * q + 4 * hh + e) * kTilePad + i];   // rows >= B hold zeros
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (t + 8 * u >= mt) break;
+            const int k = 32 * (t + 8 * u) + i;
+#pragma unroll
+            for (int q = 0; q < RT * 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 8 * q + 4 * hh + e;
+                    a[u][q][e] = (r < p.B && k < p.K) ? drop(a[u][q][e], p.in_drop, seed, r, k) : 0.f;
+                }
+            f32x16 acc;
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) acc[rg] = 0.f;
+#pragma unroll
+            for (int q = 0; q < RT * 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mfma(acc, a[u][q][e], b[q][e]);
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                const int m = 32 * (t + 8 * u) + (rg & 3) + 8 * (rg >> 2) + 4 * hh;
+                if (m < p.K) p.dW[(int64_t)m * p.N + n0 + i] = acc[rg];
             }
-        f32x16 acc;
-#pragma unroll
-        for (int rg = 0; rg < 16; ++rg) acc[rg] = 0.f;
-#pragma unroll
-        for (int q = 0; q < RT * 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) mfma(acc, a[q][e], b[q][e]);
-#pragma unroll
-        for (int rg = 0; rg < 16; ++rg) {
-            const int m = 32 * t + (rg & 3) + 8 * (rg >> 2) + 4 * hh;
-            if (m < p.K) p.dW[(int64_t)m * p.N + n0 + i] += acc[rg];
         }
     }
+    PH_MARK(11)  // weight gradient
+    PH_FLUSH
 }
 
 hipError_t t_site_fwd(const SiteFwdArgs& a, hipStream_t st) {
@@ -308,3 +386,5 @@ hipError_t t_site_bwd(const SiteBwdArgs& a, hipStream_t st) {
 }
 
 }  // namespace dptm
+
+PH_DEFINE_READER(dptm_debug_phase_cycles_site)

@@ -294,6 +294,16 @@ int dptm_trainer_get_proba(dptm_trainer* t, float* host_out, int64_t n);
  * model.fit (pred/train_PTM/trainer.py:304-309, 332-339). */
 int dptm_trainer_get_optimizer_state(dptm_trainer* t, float* m_host_out, float* v_host_out, int64_t* step_out);
 int dptm_trainer_set_optimizer_state(dptm_trainer* t, const float* m_host, const float* v_host, int64_t step);
+/* Per-kernel clocks of one training step, the trainer's counterpart of dptm_profile_begin / _end (the
+ * reference has none; Keras' own tooling would be the TensorBoard profiler callback).  Between _begin and
+ * _end the three sequence branches run one after another on one stream and each of their six launches is
+ * bracketed by HIP events on that stream.  _end waits for the device and writes DPTM_TRAIN_PROFILE_SLOTS
+ * floats, the milliseconds of the last step's launches: slot = branch * 6 + kernel with branch 0/1/2 =
+ * window 21/33/51 and kernel 0 embedding+conv-a forward, 1 conv-b forward, 2 TransformerBlocks+pooling
+ * forward, 3 TransformerBlocks+pooling backward, 4 conv-b backward, 5 conv-a+embedding backward. */
+#define DPTM_TRAIN_PROFILE_SLOTS 18
+int dptm_trainer_profile_begin(dptm_trainer* t);
+int dptm_trainer_profile_end(dptm_trainer* t, float* ms_out);
 const char* dptm_trainer_last_error(void);
 
 

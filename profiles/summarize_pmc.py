@@ -1,10 +1,18 @@
 #!/usr/bin/env python
 """profiles/summarize_pmc.py <tag>: condense gpurun_out/prof_<tag>/ (written by collect_pmc.sh) into
-profiles/<tag>_kernel_stats.csv, profiles/<tag>_bench_under_rocprof.json, profiles/<tag>_pmc_traffic.json
-and profiles/<tag>_pmc_summary.json.
+  profiles/<tag>_kernel_stats.csv, <tag>_bench_under_rocprof.json     kernel trace of the default bench
+  profiles/<tag>_pmc_traffic.json, <tag>_pmc_summary.json             W=51 scoring kernel per precision
+  profiles/<tag>_train_b<batch>_serial_kernel_stats.csv, <tag>_train_b<batch>_bench_under_rocprof.json
+  profiles/<tag>_train_pmc_traffic.json, <tag>_train_pmc_summary.json  tb_bwd_kernel<51> of the training step
+  profiles/<tag>_probe_insts.json                                      what SQ_INSTS_VALU counts (coexec_probe)
 
 HBM-side traffic per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes): on gfx950 FETCH_SIZE tallies
-the 128-byte requests of 16-byte-per-lane coalesced reads at 64 bytes, WRITE_SIZE is exact."""
+the 128-byte requests of 16-byte-per-lane coalesced reads at 64 bytes, WRITE_SIZE is exact.
+
+Issue budget of a kernel: a SIMD's issue port is held 4 clocks by a vector instruction and for its passes by
+a matrix instruction (SQ_VALU_MFMA_BUSY_CYCLES / SQ_INSTS_MFMA), and the two do not overlap
+(tools/coexec_probe.hip); SQ_INSTS_VALU counts both kinds (the probe's matrix-only kernel: see
+<tag>_probe_insts.json), so vector instructions = SQ_INSTS_VALU - SQ_INSTS_MFMA."""
 import collections
 import csv
 import glob
@@ -13,20 +21,20 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
 
 
-def per_kernel(pattern):
-    """{kernel family: {counter: [values per dispatch]}} from a counter_collection csv"""
+def per_kernel(pattern, want):
+    """{kernel family: {counter: [values per dispatch]}} from the newest counter_collection csv of a pass"""
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     files = sorted(glob.glob(os.path.join(src, pattern, "*", "*counter_collection.csv")), key=os.path.getmtime)
     for f in files[-1:]:                 # the most recent pass only (gpurun merges new files next to old ones)
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0]
-            if "branch_kernel" in name or "dense_kernel" in name:
+            if want(name):
                 agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 agg[name]["_dur_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     return agg
@@ -36,43 +44,107 @@ def mean(v):
     return sum(v) / len(v) if v else None
 
 
-def b51(agg):
+def pick(agg, *needles):
     for k, v in agg.items():
-        if "branch_kernel" in k and "51" in k:
+        if all(n in k for n in needles):
             return k, v
     return None, None
 
 
+def bench_line(name):
+    try:
+        return json.loads(open(os.path.join(src, name)).read().strip().splitlines()[-1])
+    except Exception:
+        return None
+
+
+def vector_includes_matrix():
+    """from the probe pass: the first kernel of tools/coexec_probe issues matrix instructions only"""
+    agg = per_kernel("probe", lambda n: "probe" in n)
+    out = {}
+    for k, v in agg.items():
+        if v.get("SQ_INSTS_VALU") and v.get("SQ_INSTS_MFMA"):
+            out[k] = {"SQ_INSTS_VALU": max(v["SQ_INSTS_VALU"]), "SQ_INSTS_MFMA": max(v["SQ_INSTS_MFMA"]),
+                      "SQ_ACTIVE_INST_VALU": max(v.get("SQ_ACTIVE_INST_VALU", [0])),
+                      "SQ_VALU_MFMA_BUSY_CYCLES": max(v.get("SQ_VALU_MFMA_BUSY_CYCLES", [0]))}
+    return out
+
+
+def issue_summary(k, m, units_per_launch):
+    dur = mean(m["_dur_ns"])
+    clk = mean(m["GRBM_GUI_ACTIVE"]) / 8 / dur          # GHz: the counter sums the 8 XCDs
+    busy = mean(m["SQ_VALU_MFMA_BUSY_CYCLES"])
+    n_mfma = mean(m["SQ_INSTS_MFMA"])
+    rec = {"kernel": k, "launches": len(m["_dur_ns"]), "avg_launch_us_under_pmc": dur / 1e3, "clock_ghz": clk,
+           "SQ_INSTS_MFMA_per_launch": n_mfma, "SQ_VALU_MFMA_BUSY_CYCLES_per_launch": busy,
+           "mfma_busy_frac_of_simd_cycles": busy / (1024 * dur * clk)}
+    if m.get("SQ_INSTS_VALU"):
+        n_valu = mean(m["SQ_INSTS_VALU"]) - n_mfma
+        issue = 4.0 * n_valu + busy
+        rec.update({"SQ_INSTS_VALU_per_launch": mean(m["SQ_INSTS_VALU"]),
+                    "SQ_ACTIVE_INST_VALU_per_launch": mean(m.get("SQ_ACTIVE_INST_VALU", [])),
+                    "SQ_INSTS_LDS_per_launch": mean(m.get("SQ_INSTS_LDS", [])),
+                    "SQ_WAIT_INST_ANY_per_launch": mean(m.get("SQ_WAIT_INST_ANY", [])),
+                    "mfma_cycles_per_inst": busy / n_mfma if n_mfma else None,
+                    "issue_cycles_per_launch": issue,
+                    "issue_busy_frac_of_simd_cycles": issue / (1024 * dur * clk)})
+        if units_per_launch:
+            rec.update({"units_per_launch": units_per_launch, "valu_insts_per_site": n_valu / units_per_launch,
+                        "mfma_insts_per_site": n_mfma / units_per_launch, "issue_cycles_per_site": issue / units_per_launch})
+    return rec
+
+
+# ---------------------------------------------------------------- scoring kernels, per precision
+is_score = lambda n: "branch_kernel" in n or "dense_kernel" in n
 traffic, summary = {}, {}
-for prec in ("f32", "f16x3", "bf16"):
-    kf, f = b51(per_kernel("fetch_" + prec))
-    kw, w = b51(per_kernel("write_" + prec))
-    km, m = b51(per_kernel("mfma_" + prec))
+for prec in ("f32", "f16x3", "f16", "bf16"):
+    kf, f = pick(per_kernel("fetch_" + prec, is_score), "branch_kernel", "51")
+    kw, w = pick(per_kernel("write_" + prec, is_score), "branch_kernel", "51")
+    km, m = pick(per_kernel("mfma_" + prec, is_score), "branch_kernel", "51")
     if not f or not w:
         continue
-    try:
-        line = json.loads(open(os.path.join(src, "fetch_%s.json" % prec)).read().strip().splitlines()[-1])
-        spl = line["roofline"]["sites_per_launch"]
-    except Exception:
-        spl = None
+    line = bench_line("fetch_%s.json" % prec)
+    spl = line["roofline"]["sites_per_launch"] if line else None
     fetch_kib, write_kib = mean(f["FETCH_SIZE"]), mean(w["WRITE_SIZE"])
     traffic[prec] = {"kernel": kf, "launches": len(f["FETCH_SIZE"]), "sites_per_launch": spl,
                      "FETCH_SIZE_KiB_per_launch": fetch_kib, "WRITE_SIZE_KiB_per_launch": write_kib,
                      "traffic_bytes_per_launch": (2 * fetch_kib + write_kib) * 1024}
     if m:
-        dur = mean(m["_dur_ns"])
-        clk = mean(m["GRBM_GUI_ACTIVE"]) / 8 / dur          # GHz: the counter sums the 8 XCDs
-        busy = mean(m["SQ_VALU_MFMA_BUSY_CYCLES"])
-        summary[prec] = {"kernel": km, "avg_launch_us_under_pmc": dur / 1e3, "clock_ghz": clk,
-                         "SQ_INSTS_MFMA_per_launch": mean(m["SQ_INSTS_MFMA"]),
-                         "SQ_VALU_MFMA_BUSY_CYCLES_per_launch": busy,
-                         "mfma_busy_frac_of_simd_cycles": busy / (1024 * dur * clk)}
-json.dump(traffic, open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1)
-json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1)
+        summary[prec] = issue_summary(km, m, spl)
+if traffic:
+    json.dump(traffic, open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1)
+    json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1)
 for f in sorted(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")), key=os.path.getmtime)[-1:]:
     shutil.copy(f, os.path.join(dst, tag + "_kernel_stats.csv"))
 tb = os.path.join(src, "trace_bench.json")
-if os.path.exists(tb):
+if os.path.exists(tb) and bench_line("trace_bench.json"):
     shutil.copy(tb, os.path.join(dst, tag + "_bench_under_rocprof.json"))
-print(json.dumps(traffic, indent=1))
-print(json.dumps(summary, indent=1))
+
+# ---------------------------------------------------------------- training step
+is_train = lambda n: "tb_" in n or "conv_" in n
+ttraffic, tsummary = {}, {}
+for batch in (8192, 64):
+    b = "b%d" % batch
+    for f in sorted(glob.glob(os.path.join(src, "train_trace_" + b, "*", "*kernel_stats.csv")), key=os.path.getmtime)[-1:]:
+        shutil.copy(f, os.path.join(dst, "%s_train_%s_serial_kernel_stats.csv" % (tag, b)))
+    if bench_line("train_trace_%s.json" % b):
+        shutil.copy(os.path.join(src, "train_trace_%s.json" % b), os.path.join(dst, "%s_train_%s_bench_under_rocprof.json" % (tag, b)))
+    kf, f = pick(per_kernel("train_fetch_" + b, is_train), "tb_bwd_kernel", "<51")
+    kw, w = pick(per_kernel("train_write_" + b, is_train), "tb_bwd_kernel", "<51")
+    km, m = pick(per_kernel("train_mfma_" + b, is_train), "tb_bwd_kernel", "<51")
+    if f and w:
+        fetch_kib, write_kib = mean(f["FETCH_SIZE"]), mean(w["WRITE_SIZE"])
+        ttraffic["batch%d" % batch] = {"kernel": kf, "launches": len(f["FETCH_SIZE"]), "sites_per_launch": batch,
+                                       "FETCH_SIZE_KiB_per_launch": fetch_kib, "WRITE_SIZE_KiB_per_launch": write_kib,
+                                       "traffic_bytes_per_launch": (2 * fetch_kib + write_kib) * 1024}
+    if m:
+        tsummary["batch%d" % batch] = issue_summary(km, m, batch)
+if ttraffic:
+    json.dump(ttraffic, open(os.path.join(dst, tag + "_train_pmc_traffic.json"), "w"), indent=1)
+if tsummary:
+    json.dump(tsummary, open(os.path.join(dst, tag + "_train_pmc_summary.json"), "w"), indent=1)
+
+probe = vector_includes_matrix()
+if probe:
+    json.dump(probe, open(os.path.join(dst, tag + "_probe_insts.json"), "w"), indent=1)
+print(json.dumps({"traffic": traffic, "summary": summary, "train_traffic": ttraffic, "train_summary": tsummary, "probe": probe}, indent=1))
