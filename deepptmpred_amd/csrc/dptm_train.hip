@@ -7,6 +7,7 @@
 #include <memory>
 #include <new>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -481,6 +482,66 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
     return DPTM_OK;
 }
 
+// ------------------------------------------------------------------------------------ streams of a trainer
+// A process has four hardware queues and the runtime maps every new stream to the queue with the fewest streams
+// on it, so whether four new streams land on four DIFFERENT queues depends on what else the process has created
+// and destroyed; two busy streams on one queue serialise, and the step's lanes then run one after another.
+// There is no call that tells a stream's queue, so the trainer finds out by timing: two streams on one queue
+// take twice as long over a pair of fixed-duration kernels as two streams on different queues.
+
+__global__ void spin_kernel(unsigned long long ticks) {       // returns after `ticks` of the 100 MHz wall clock
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+bool streams_serialise(hipStream_t a, hipStream_t b) {
+    constexpr unsigned long long kTicks = 15000;              // 150 us
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, kTicks);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, kTicks);
+    (void)hipStreamSynchronize(a);
+    (void)hipStreamSynchronize(b);
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    return us > 1.6 * 150.0;
+}
+
+// t->stream and t->aux[0..2]: four streams on four different hardware queues when the process has that many
+hipError_t pick_streams(dptm_trainer* t) {
+    constexpr int kCandidates = 8;
+    hipStream_t cand[kCandidates] = {};
+    hipStream_t chosen[4] = {};
+    int n_chosen = 0, n_cand = 0;
+    hipError_t err = hipSuccess;
+    for (; n_cand < kCandidates && n_chosen < 4; ++n_cand) {
+        err = hipStreamCreateWithFlags(&cand[n_cand], hipStreamNonBlocking);
+        if (err != hipSuccess) break;
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, cand[n_cand], 0ull);      // first use binds the queue
+        bool fresh = true;
+        for (int k = 0; k < n_chosen && fresh; ++k) fresh = !streams_serialise(cand[n_cand], chosen[k]);
+        if (fresh) {
+            chosen[n_chosen++] = cand[n_cand];
+            cand[n_cand] = nullptr;
+        }
+    }
+    // fewer than four queues found: the remaining lanes share streams already chosen, the rest is given back
+    for (int k = 0; k < kCandidates; ++k) {
+        if (!cand[k]) continue;
+        if (n_chosen < 4 && err == hipSuccess)
+            chosen[n_chosen++] = cand[k];
+        else
+            (void)hipStreamDestroy(cand[k]);
+    }
+    if (n_chosen == 0) return err != hipSuccess ? err : hipErrorUnknown;
+    while (n_chosen < 4) {
+        if (hipStreamCreateWithFlags(&chosen[n_chosen], hipStreamNonBlocking) != hipSuccess) return hipErrorUnknown;
+        ++n_chosen;
+    }
+    t->stream = chosen[0];
+    for (int b = 0; b < 3; ++b) t->aux[b] = chosen[1 + b];
+    return hipSuccess;
+}
+
 }  // namespace
 
 // a C++ exception must not leave an extern "C" function (see the function-try-blocks below)
@@ -547,11 +608,7 @@ int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spe
     t->max_batch = max_batch;
     auto bail = [&](int code, const char* msg) { return tfail(code, msg); };   // `owner` frees the half-built trainer
     if (hipSetDevice(device) != hipSuccess) return bail(DPTM_EINVAL, "dptm_trainer_create: no such device");
-    // four streams created back to back: the runtime hands out its hardware queues in turn, so the four land on
-    // four different queues (streams of the caller's that share one of them are idle while a step runs)
-    if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) return bail(DPTM_EHIP, "hipStreamCreate failed");
-    for (int b = 0; b < 3; ++b)
-        if (hipStreamCreateWithFlags(&t->aux[b], hipStreamNonBlocking) != hipSuccess) return bail(DPTM_EHIP, "hipStreamCreate failed");
+    if (pick_streams(t) != hipSuccess) return bail(DPTM_EHIP, "hipStreamCreate failed");
     for (int ph = 0; ph < 2; ++ph) {
         if (hipEventCreateWithFlags(&t->ev_fork[ph], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&t->ev_caller[ph], hipEventDisableTiming) != hipSuccess)
