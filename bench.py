@@ -690,11 +690,12 @@ def main() -> None:
             "kernel_ms_per_step": {k: round(v[0], 3) for k, v in prof.items()},
             "kernel_ms_total": round(total_kernel_ms, 3),
         }
-        if args.precision != "f32":
-            ib = issue_bound(args.precision, sites_per_launch, avg_s)
-            if ib:       # the half-precision kernels are issue-bound: the matrix-peak fraction stays beside it
-                line["roofline_mfma"] = line["roofline"]
-                line["roofline"] = dict(ib, traffic=traffic, avg_launch_ms=avg_s * 1e3, sites_per_launch=sites_per_launch)
+        ib = issue_bound(args.precision, sites_per_launch, avg_s)
+        if ib and args.precision != "f32":       # the half-precision kernels are issue-bound: the matrix-peak fraction stays beside it
+            line["roofline_mfma"] = line["roofline"]
+            line["roofline"] = dict(ib, traffic=traffic, avg_launch_ms=avg_s * 1e3, sites_per_launch=sites_per_launch)
+        elif ib:                                 # fp32: matrix-bound; the issue-slot budget (matrix + vector) beside it
+            line["roofline_issue"] = ib
         if variants:
             line["variants"] = variants
         line.update(extras)

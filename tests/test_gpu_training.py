@@ -47,8 +47,11 @@ def _compare_grads(got_blob, want, label):
 # The fused TransformerBlock kernels tile a branch by whole sites in 1, 2, 4 or 8 wavefronts, the tile growing with the
 # batch: 600 sites take the two- and four-wavefront tiles (and more tiles than workgroups, so partial gradients are
 # accumulated over several tiles), 2,411 sites the eight-wavefront tiles with a ragged last tile.
-@pytest.mark.parametrize("rates,n", [((0.0, 0.0, 0.0, 0.0), 48), ((1e-4, 0.3, 0.1, 0.3), 48), ((1e-4, 0.3, 0.1, 0.3), 230),
-                                     ((1e-4, 0.3, 0.1, 0.3), 600), ((1e-4, 0.3, 0.1, 0.3), 2411)])
+# 100 sites: the four-row-tile instance of the small-batch per-site kernels (65..128 sites); 4,100 sites: the per-site
+# layers' LDS-staged products (row stacks of 4,096 and more) and more eight-wavefront tiles than workgroups.
+@pytest.mark.parametrize("rates,n", [((0.0, 0.0, 0.0, 0.0), 48), ((1e-4, 0.3, 0.1, 0.3), 48), ((1e-4, 0.3, 0.1, 0.3), 100),
+                                     ((1e-4, 0.3, 0.1, 0.3), 230), ((1e-4, 0.3, 0.1, 0.3), 600), ((1e-4, 0.3, 0.1, 0.3), 2411),
+                                     ((1e-4, 0.3, 0.1, 0.3), 4100)])
 def test_gradients_match_autograd(rates, n):
     import torch
     w = spec.synthetic_weights(7)
