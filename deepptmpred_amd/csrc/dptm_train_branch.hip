@@ -69,9 +69,12 @@ hipError_t t_pack(const PackJob* jobs_dev, int n_jobs, hipStream_t st) {
 namespace {
 struct Cand { int S, NW; };
 // candidates per window size, largest tile first; NW in {1, 2, 4, 8} so that the weight-gradient blocks divide evenly
-const Cand kCand21[] = {{12, 8}, {6, 4}, {3, 2}, {1, 1}};
-const Cand kCand33[] = {{7, 8}, {3, 4}, {1, 2}};
-const Cand kCand51[] = {{5, 8}, {2, 4}, {1, 2}};
+// The last entry serves batches too small for any other: one site in FOUR wavefronts.  The wavefronts without rows
+// of their own take a share of every weight-gradient unit (whose contraction stops at the site's last row), so the
+// dependent chain of the wavefronts that do hold rows -- which is what such a launch lasts -- gets shorter.
+const Cand kCand21[] = {{12, 8}, {6, 4}, {3, 2}, {1, 1}, {1, 4}};
+const Cand kCand33[] = {{7, 8}, {3, 4}, {1, 2}, {1, 4}};
+const Cand kCand51[] = {{5, 8}, {2, 4}, {1, 2}, {1, 4}};
 // take the largest tile that still gives this many workgroups (DPTM_TRAIN_MIN_TILES overrides: tests use it to
 // run the large tiles on small batches)
 int64_t min_tiles() {
@@ -86,7 +89,7 @@ int64_t min_tiles() {
 
 TileCfg t_tile_cfg(int64_t n, int wlen) {
     const Cand* c = wlen == 21 ? kCand21 : wlen == 33 ? kCand33 : kCand51;
-    const int nc = wlen == 21 ? 4 : 3;
+    const int nc = wlen == 21 ? 5 : 4;
     TileCfg r{c[nc - 1].S, c[nc - 1].NW, 0};
     for (int i = 0; i < nc; ++i)
         if ((n + c[i].S - 1) / c[i].S >= min_tiles()) {
@@ -101,7 +104,7 @@ TileCfg t_tile_cfg(int64_t n, int wlen) {
 int64_t t_tile_rows_max(int64_t max_sites, int wlen) {
     // the padded row count grows with n inside one (S, NW) regime: its maximum sits at a regime's upper end
     const Cand* c = wlen == 21 ? kCand21 : wlen == 33 ? kCand33 : kCand51;
-    const int nc = wlen == 21 ? 4 : 3;
+    const int nc = wlen == 21 ? 5 : 4;
     int64_t best = 0;
     for (int i = 0; i < nc; ++i) {
         // largest n (<= max_sites) that still selects candidate i: below the threshold of every larger tile
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
                 }
                 PH_MARK(2)   // feed-forward row products
                 TB_SYNC();
-                dw_unit_t(bufA, bufB, NW, xreg, pu + (4 + c) * 4096, first, lane, wave);     // dW2[chunk, :] += u_c^T d(f2)
+                dw_unit_t<MAXT == 256>(bufA, bufB, NW, xreg, pu + (4 + c) * 4096, first, lane, wave, rows_valid);     // dW2[chunk, :] += u_c^T d(f2)
                 PH_MARK(3)   // feed-forward weight gradients
                 chain_store_t(lane_a, hx);
                 chain_store_t(lane_b, d1);
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
                 gemm_k256_chunk(acc_dh, TT + kBtW1T, c, d1, lane);                         // d(h) += d(f1_c) W1[:, chunk]^T
                 PH_MARK(2)
                 TB_SYNC();
-                dw_unit_t(bufA, bufB, NW, xreg, pu + c * 4096, first, lane, wave);           // dW1[:, chunk] += h^T d(f1_c)
+                dw_unit_t<MAXT == 256>(bufA, bufB, NW, xreg, pu + c * 4096, first, lane, wave, rows_valid);           // dW1[:, chunk] += h^T d(f1_c)
                 PH_MARK(3)
             }
             PH_MARK(2)
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
                 wave_fence();
                 atomicAdd(va + kSBo * 64, colsum32_t(bufB, row0, lane));
                 TB_SYNC();
-                dw_unit_t(bufA, bufB, NW, xreg, pu + 8 * 4096, first, lane, wave);           // dWo += o^T d(ao)
+                dw_unit_t<MAXT == 256>(bufA, bufB, NW, xreg, pu + 8 * 4096, first, lane, wave, rows_valid);           // dWo += o^T d(ao)
                 f32x16 acc[2];
                 acc_zero<2>(acc);
                 gemm_regs<8, 2>(acc, TT + kBtWoT, dao, lane);                              // d(o) = d(ao) Wo^T
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
                 wave_fence();
                 atomicAdd(va + kSBq * 64, colsum32_t(bufB, row0, lane));
                 TB_SYNC();
-                dw_unit_t(bufA, bufB, NW, xreg, pu + 9 * 4096, first, lane, wave);           // dWq += x^T dq
+                dw_unit_t<MAXT == 256>(bufA, bufB, NW, xreg, pu + 9 * 4096, first, lane, wave, rows_valid);           // dWq += x^T dq
                 x_to_acc(dsum, acc_dx);
                 gemm_regs<8, 2>(acc_dx, TT + kBtWqT, dq, lane);
             }
@@ -711,13 +714,13 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
                 wave_fence();
                 atomicAdd(va + kSBk * 64, colsum32_t(bufB, row0, lane));
                 TB_SYNC();
-                dw_unit_t(bufA, bufB, NW, xreg, pu + 10 * 4096, first, lane, wave);          // dWk += x^T dk
+                dw_unit_t<MAXT == 256>(bufA, bufB, NW, xreg, pu + 10 * 4096, first, lane, wave, rows_valid);          // dWk += x^T dk
                 gemm_regs<8, 2>(acc_dx, TT + kBtWkT, dk, lane);
                 chain_store_t(lane_b, dv);
                 wave_fence();
                 atomicAdd(va + kSBv * 64, colsum32_t(bufB, row0, lane));
                 TB_SYNC();
-                dw_unit_t(bufA, bufB, NW, xreg, pu + 11 * 4096, first, lane, wave);          // dWv += x^T dv
+                dw_unit_t<MAXT == 256>(bufA, bufB, NW, xreg, pu + 11 * 4096, first, lane, wave, rows_valid);          // dWv += x^T dv
                 gemm_regs<8, 2>(acc_dx, TT + kBtWvT, dv, lane);
             }
             acc_to_x<2>(acc_dx, dy);

@@ -83,13 +83,15 @@ __device__ __forceinline__ void embed_tile(const ConvArgs& p, float* img, int ro
 
 // The weight-gradient unit of dw_unit for one tap of a convolution: part_u (+)= shift(X)^T Y where row r of Y
 // meets row r + xshift of X when that row lies in the same site (positions 0..W-1), zero otherwise.
-template <int W>
+template <int W, bool SHORT>
 __device__ __forceinline__ void dw_unit_tap(const float* imgX, const float* imgY, int xshift, int NW, float* xchg,
-                                            float* __restrict__ part_u, bool first, int lane, int wave) {
+                                            float* __restrict__ part_u, bool first, int lane, int wave, int rows_valid) {
     const int hh = lane >> 5, i = lane & 31;
     const int nblk = NW >= 4 ? 1 : 4 / NW;                 // blocks per wavefront
     const int sp = NW >= 4 ? wave >> 2 : 0;                // row half (NW = 8)
-    const int rows = NW >= 4 ? 128 : NW * 32;              // rows this wavefront contracts over
+    // rows this wavefront contracts over; a four-wavefront tile that is mostly padding (one site, the shape small
+    // batches take) stops at its last valid row: the rows behind it hold zeros in both images
+    const int rows = SHORT && NW == 4 && rows_valid <= 96 ? rows_valid + (rows_valid & 1) : NW >= 4 ? 128 : NW * 32;
     for (int bi = 0; bi < nblk; ++bi) {
         const int b = NW >= 4 ? (wave & 3) : wave * nblk + bi;
         const int r0 = sp * 128 + hh;
@@ -332,7 +334,8 @@ constexpr int kCbVec = 3 * 4096;
 constexpr int kCaVec = 4 * 4096, kCaEmb = kCaVec + 128, kCaPos = kCaEmb + kCodes * 64;
 static_assert(kCaPos + kMaxW * 64 <= kTbPartStride, "the convolution kernels share the TransformerBlock kernel's partial buffer");
 
-template <int W>
+// SHORT: the instance for tiles of fewer than eight wavefronts (small batches), see dw_unit
+template <int W, bool SHORT>
 __global__ __launch_bounds__(512) void conv_b_bwd_kernel(ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int NW = blockDim.x >> 6, rows_tile = NW * 32;
@@ -409,11 +412,11 @@ __global__ __launch_bounds__(512) void conv_b_bwd_kernel(ConvArgs p) {
             for (int u = 0; u < 8; ++u) p.dz1[ct + u * 64] = dz1[u];
         }
         // dK[t] += shift_{t-1}(z1)^T d(a2)
-        dw_unit_tap<W>(bufA, bufB, -1, NW, xreg, part + 0 * 4096, first, lane, wave);
+        dw_unit_tap<W, SHORT>(bufA, bufB, -1, NW, xreg, part + 0 * 4096, first, lane, wave, rows_valid);
         __syncthreads();   // the exchange buffer of the previous unit has been read
-        dw_unit(bufA, bufB, NW, xreg, part + 1 * 4096, first, lane, wave);
+        dw_unit<SHORT>(bufA, bufB, NW, xreg, part + 1 * 4096, first, lane, wave, rows_valid);
         __syncthreads();
-        dw_unit_tap<W>(bufA, bufB, +1, NW, xreg, part + 2 * 4096, first, lane, wave);
+        dw_unit_tap<W, SHORT>(bufA, bufB, +1, NW, xreg, part + 2 * 4096, first, lane, wave, rows_valid);
         __syncthreads();
         // column sums for BN1's backward pass: d(z1) and d(z1) * swish(a1), through the wavefront's own image rows
         {
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(512) void conv_b_bwd_kernel(ConvArgs p) {
     }
 }
 
-template <int W>
+template <int W, bool SHORT>
 __global__ __launch_bounds__(512) void conv_a_bwd_kernel(ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int NW = blockDim.x >> 6, rows_tile = NW * 32;
@@ -495,11 +498,11 @@ __global__ __launch_bounds__(512) void conv_a_bwd_kernel(ConvArgs p) {
             taps3(acc, p.PT + kBtC3aT, p.PT + kBtC3aT + 1024, p.PT + kBtC3aT + 2048, tap2_ok ? xc + kLdsStride : xc, xc,
                   tap0_ok ? xc - kLdsStride : xc, tap2_ok, tap0_ok, lane);
         }
-        dw_unit_tap<W>(bufA, bufB, -1, NW, xreg, part + 0 * 4096, first, lane, wave);
+        dw_unit_tap<W, SHORT>(bufA, bufB, -1, NW, xreg, part + 0 * 4096, first, lane, wave, rows_valid);
         __syncthreads();   // the exchange buffer of the previous unit has been read
-        dw_unit(bufA, bufB, NW, xreg, part + 1 * 4096, first, lane, wave);
+        dw_unit<SHORT>(bufA, bufB, NW, xreg, part + 1 * 4096, first, lane, wave, rows_valid);
         __syncthreads();
-        dw_unit_tap<W>(bufA, bufB, +1, NW, xreg, part + 2 * 4096, first, lane, wave);
+        dw_unit_tap<W, SHORT>(bufA, bufB, +1, NW, xreg, part + 2 * 4096, first, lane, wave, rows_valid);
         __syncthreads();
         f32x4 dx0[8];
         {
@@ -510,7 +513,7 @@ __global__ __launch_bounds__(512) void conv_a_bwd_kernel(ConvArgs p) {
             wave_fence();
             atomicAdd(&vacc[64 + lane], colsum32(own_b, lane));
             __syncthreads();
-            dw_unit(bufA, bufB, NW, xreg, part + 3 * 4096, first, lane, wave);       // dKsc += x0^T d(x1)
+            dw_unit<SHORT>(bufA, bufB, NW, xreg, part + 3 * 4096, first, lane, wave, rows_valid);       // dKsc += x0^T d(x1)
             gemm_regs<8, 2>(acc, p.PT + kBtScT, d1, lane);
             acc_to_x<2>(acc, dx0);
         }
@@ -565,6 +568,19 @@ static hipError_t launch_conv(K kernel, bool (&done)[64], const ConvArgs& a, int
         default: e = launch_conv(&KERNEL<51>, d51, a, NW, LDS, LDS_MAX, MAX_GRID, st); break;                     \
     }
 
+// backward kernels: a second instance for tiles of fewer than eight wavefronts
+#define DPTM_CONV_DISPATCH_BWD(KERNEL, LDS, LDS_MAX, MAX_GRID)                                                    \
+    static bool d21[64] = {}, d33[64] = {}, d51[64] = {}, s21[64] = {}, s33[64] = {}, s51[64] = {};               \
+    const bool small_tile = NW < 8;                                                                               \
+    switch (wlen) {                                                                                               \
+        case 21: e = small_tile ? launch_conv(&KERNEL<21, true>, s21, a, NW, LDS, LDS_MAX, MAX_GRID, st)          \
+                                : launch_conv(&KERNEL<21, false>, d21, a, NW, LDS, LDS_MAX, MAX_GRID, st); break; \
+        case 33: e = small_tile ? launch_conv(&KERNEL<33, true>, s33, a, NW, LDS, LDS_MAX, MAX_GRID, st)          \
+                                : launch_conv(&KERNEL<33, false>, d33, a, NW, LDS, LDS_MAX, MAX_GRID, st); break; \
+        default: e = small_tile ? launch_conv(&KERNEL<51, true>, s51, a, NW, LDS, LDS_MAX, MAX_GRID, st)          \
+                                : launch_conv(&KERNEL<51, false>, d51, a, NW, LDS, LDS_MAX, MAX_GRID, st); break; \
+    }
+
 hipError_t t_conv_a_fwd(const ConvArgs& a, int wlen, int NW, hipStream_t st) {
     if (a.n_sites == 0) return hipSuccess;
     if (!tile_ok(wlen, a.S, NW, a.n_sites, a.ntiles)) return hipErrorInvalidValue;
@@ -585,7 +601,7 @@ hipError_t t_conv_b_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW,
     if (a.n_sites == 0) return hipSuccess;
     if (!tile_ok(wlen, a.S, NW, a.n_sites, a.ntiles)) return hipErrorInvalidValue;
     hipError_t e;
-    DPTM_CONV_DISPATCH(conv_b_bwd_kernel, conv_bwd_lds(NW), conv_bwd_lds(8), kTbMaxParts)
+    DPTM_CONV_DISPATCH_BWD(conv_b_bwd_kernel, conv_bwd_lds(NW), conv_bwd_lds(8), kTbMaxParts)
     if (e != hipSuccess) return e;
     const int grid = (int)(a.ntiles < kTbMaxParts ? a.ntiles : kTbMaxParts);
     PartUnits ut;
@@ -604,7 +620,7 @@ hipError_t t_conv_a_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW,
     if (a.n_sites == 0) return hipSuccess;
     if (!tile_ok(wlen, a.S, NW, a.n_sites, a.ntiles)) return hipErrorInvalidValue;
     hipError_t e;
-    DPTM_CONV_DISPATCH(conv_a_bwd_kernel, conv_bwd_lds(NW), conv_bwd_lds(8), kTbMaxParts)
+    DPTM_CONV_DISPATCH_BWD(conv_a_bwd_kernel, conv_bwd_lds(NW), conv_bwd_lds(8), kTbMaxParts)
     if (e != hipSuccess) return e;
     const int grid = (int)(a.ntiles < kTbMaxParts ? a.ntiles : kTbMaxParts);
     PartUnits ut;

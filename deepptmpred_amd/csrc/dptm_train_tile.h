@@ -208,8 +208,11 @@ __device__ __forceinline__ void ln_backward(const f32x4 (&dy)[8], const f32x4 (&
 // caller has put a barrier between writing the images and this call; the call ends with one barrier, after which
 // the images (not xchg) may be overwritten.  xchg: 4096 floats of LDS that nothing else uses across the call.
 // part_u: this workgroup's 4096 floats for the unit, accumulator order [block][register][lane].
+// Rows at and beyond `rows_valid` hold zeros in both images (padding rows of a tile).  SHORT (the instances that
+// small batches run): in a tile that is mostly padding -- one site in four wavefronts -- the contraction stops there.
+template <bool SHORT>
 __device__ __forceinline__ void dw_unit(const float* imgX, const float* imgY, int NW, float* xchg, float* __restrict__ part_u,
-                                        bool first, int lane, int wave) {
+                                        bool first, int lane, int wave, int rows_valid) {
     const int hh = lane >> 5, i = lane & 31;
     if (NW >= 4) {
         // wavefront w: block w & 3 over row half w >> 2 (NW = 4: one "half" of all 128 rows)
@@ -224,8 +227,14 @@ __device__ __forceinline__ void dw_unit(const float* imgX, const float* imgY, in
 #pragma unroll
             for (int rg = 0; rg < 16; ++rg) acc[rg] = dst[rg * 64];
         }
+        if (!SHORT || rows_valid > sp * 128 + 96) {
 #pragma unroll 8
-        for (int q = 0; q < 64; ++q) mfma(acc, ap[2 * q * kLdsStride], bp[2 * q * kLdsStride]);
+            for (int q = 0; q < 64; ++q) mfma(acc, ap[2 * q * kLdsStride], bp[2 * q * kLdsStride]);
+        } else {
+            const int nsteps = max(0, (rows_valid - sp * 128 + 1) >> 1);
+#pragma unroll 1
+            for (int q = 0; q < nsteps; ++q) mfma(acc, ap[2 * q * kLdsStride], bp[2 * q * kLdsStride]);
+        }
         if (sp == 1) {
 #pragma unroll
             for (int rg = 0; rg < 16; ++rg) xchg[(b * 16 + rg) * 64 + lane] = acc[rg];
@@ -266,12 +275,17 @@ __device__ __forceinline__ void dw_unit(const float* imgX, const float* imgY, in
 #endif
 // dw_unit on transposed images: one 16-byte read per operand feeds four MFMA steps.  Step s of group Q contracts
 // rows 8Q + s (lower half-wave) and 8Q + 4 + s (upper half-wave); every row of the tile is met once.
+// Rows at and beyond `rows_valid` hold zeros in both images (padding rows of a tile).  SHORT (the instances that
+// small batches run): in a four-wavefront tile that is mostly padding -- one site -- the contraction stops at the
+// group of 8 rows that holds the last valid one.
+template <bool SHORT>
 __device__ __forceinline__ void dw_unit_t(const float* imgXT, const float* imgYT, int NW, float* xchg,
-                                          float* __restrict__ part_u, bool first, int lane, int wave) {
+                                          float* __restrict__ part_u, bool first, int lane, int wave, int rows_valid) {
     const int hh = lane >> 5, i = lane & 31;
     const int nblk = NW >= 4 ? 1 : 4 / NW;                 // blocks per wavefront
     const int sp = NW >= 4 ? wave >> 2 : 0;                // row half (NW = 8)
-    const int nq = NW >= 4 ? 16 : NW * 4;                  // groups of 8 rows this wavefront contracts over
+    int nq = NW >= 4 ? 16 : NW * 4;                        // groups of 8 rows this wavefront contracts over
+    if (SHORT && NW == 4 && rows_valid <= 96) nq = (rows_valid + 7) >> 3;
     for (int bi = 0; bi < nblk; ++bi) {
         const int b = NW >= 4 ? (wave & 3) : wave * nblk + bi;
         const float* ap = imgXT + (32 * (b >> 1) + i) * kTs + sp * 128 + 4 * hh;
