@@ -87,11 +87,16 @@ int64_t min_tiles() {
 }
 }  // namespace
 
+// batches up to this many sites take the last candidate: the three branches' workgroups (one per CU: a four-wavefront
+// tile holds 91 KB of LDS) then still run side by side on the chip's 256 CUs
+constexpr int64_t kLatencyTileSites = 85;
+
 TileCfg t_tile_cfg(int64_t n, int wlen) {
     const Cand* c = wlen == 21 ? kCand21 : wlen == 33 ? kCand33 : kCand51;
     const int nc = wlen == 21 ? 5 : 4;
-    TileCfg r{c[nc - 1].S, c[nc - 1].NW, 0};
-    for (int i = 0; i < nc; ++i)
+    const int fallback = n <= kLatencyTileSites ? nc - 1 : nc - 2;
+    TileCfg r{c[fallback].S, c[fallback].NW, 0};
+    for (int i = 0; i < nc - 1; ++i)
         if ((n + c[i].S - 1) / c[i].S >= min_tiles()) {
             r.S = c[i].S;
             r.NW = c[i].NW;
@@ -109,7 +114,10 @@ int64_t t_tile_rows_max(int64_t max_sites, int wlen) {
     for (int i = 0; i < nc; ++i) {
         // largest n (<= max_sites) that still selects candidate i: below the threshold of every larger tile
         int64_t hi = max_sites;
-        if (i > 0) hi = hi < (min_tiles() - 1) * c[i - 1].S ? hi : (min_tiles() - 1) * c[i - 1].S;
+        if (i == nc - 1)
+            hi = hi < kLatencyTileSites ? hi : kLatencyTileSites;
+        else if (i > 0)
+            hi = hi < (min_tiles() - 1) * c[i - 1].S ? hi : (min_tiles() - 1) * c[i - 1].S;
         if (hi < 1) continue;
         const TileCfg t = t_tile_cfg(hi, wlen);
         const int64_t rows = t.ntiles * t.NW * 32;

@@ -311,47 +311,58 @@ __global__ __launch_bounds__(512) void site_bwd_kernel(SiteBwdArgs p) {
     // (rows 8q + 4hh + e meet in step 4q + e; all loads of a block are requested before its first product)
     PH_MARK(10)  // bias gradient
     // Several blocks per pass, so that their loads are all in flight; this kernel is the only writer of its dW columns.
-    constexpr int U = RT <= 1 ? 4 : RT == 2 ? 3 : 1;
+    // The batch rows are walked in slices of at most 64 (QS groups of 8), so that a pass holds at most 96 operands.
+    constexpr int U = RT <= 1 ? 4 : RT == 2 ? 3 : 2;
+    constexpr int QS = RT * 4 < 8 ? RT * 4 : 8;
     const int mt = (p.K + 31) / 32;
     for (int t = wave; t < mt; t += 8 * U) {
-        f32x4 a[U][RT * 4], b[RT * 4];
+        f32x16 acc[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int kc = min(32 * (t + 8 * u) + i, p.K - 1);
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int q = 0; q < RT * 4; ++q)
+            for (int rg = 0; rg < 16; ++rg) acc[u][rg] = 0.f;
+#pragma unroll 1
+        for (int q0 = 0; q0 < RT * 4; q0 += QS) {
+            f32x4 a[U][QS], b[QS];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 8 * q + 4 * hh + e;
-                    a[u][q][e] = p.x[(int64_t)min(r, p.B - 1) * p.ldx + kc];      // all loads first, masks afterwards
-                }
+            for (int u = 0; u < U; ++u) {
+                const int kc = min(32 * (t + 8 * u) + i, p.K - 1);
+#pragma unroll
+                for (int q = 0; q < QS; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 8 * (q0 + q) + 4 * hh + e;
+                        a[u][q][e] = p.x[(int64_t)min(r, p.B - 1) * p.ldx + kc];      // all loads first, masks afterwards
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < QS; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[q][e] = tile[(8 * (q0 + q) + 4 * hh + e) * kTilePad + i];   // rows >= B hold zeros
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (t + 8 * u >= mt) break;
+                const int k = 32 * (t + 8 * u) + i;
+#pragma unroll
+                for (int q = 0; q < QS; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 8 * (q0 + q) + 4 * hh + e;
+                        a[u][q][e] = (r < p.B && k < p.K) ? drop(a[u][q][e], p.in_drop, seed, r, k) : 0.f;
+                    }
+#pragma unroll
+                for (int q = 0; q < QS; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mfma(acc[u], a[u][q][e], b[q][e]);
+            }
         }
-#pragma unroll
-        for (int q = 0; q < RT * 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) b[q][e] = tile[(8 * q + 4 * hh + e) * kTilePad + i];   // rows >= B hold zeros
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (t + 8 * u >= mt) break;
-            const int k = 32 * (t + 8 * u) + i;
-#pragma unroll
-            for (int q = 0; q < RT * 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 8 * q + 4 * hh + e;
-                    a[u][q][e] = (r < p.B && k < p.K) ? drop(a[u][q][e], p.in_drop, seed, r, k) : 0.f;
-                }
-            f32x16 acc;
-#pragma unroll
-            for (int rg = 0; rg < 16; ++rg) acc[rg] = 0.f;
-#pragma unroll
-            for (int q = 0; q < RT * 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) mfma(acc, a[u][q][e], b[q][e]);
 #pragma unroll
             for (int rg = 0; rg < 16; ++rg) {
                 const int m = 32 * (t + 8 * u) + (rg & 3) + 8 * (rg >> 2) + 4 * hh;
-                if (m < p.K) p.dW[(int64_t)m * p.N + n0 + i] = acc[rg];
+                if (m < p.K) p.dW[(int64_t)m * p.N + n0 + i] = acc[u][rg];
             }
         }
     }
