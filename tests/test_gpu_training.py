@@ -234,3 +234,35 @@ def test_replicas_with_synchronised_batchnorm_equal_one_device():
         worst = max(float(np.abs(w1[k] - w2[k]).max()) for k in w1)
         print("one device vs", label, ": max weight difference", worst)
         assert worst < 1e-4, label      # Adam divides by |g|: float-atomic noise on a near-zero gradient moves a weight by a fraction of lr = 5e-4
+
+
+def test_trainer_profile_times_the_branch_launches():
+    """dptm_trainer_profile_begin / _end: one duration per sequence-branch launch of the last step, and the step
+    gives the same gradients whether its branches ran side by side or, under the profile, one after another."""
+    import torch
+    n = 40
+    w = spec.synthetic_weights(3)
+    x = spec.synthetic_inputs(n, 11)
+    y = (np.random.default_rng(2).random(n) < 0.3).astype(np.int64)
+    tr = _native.Trainer(spec.pack_blob(w), max_batch=64)
+    d, lab = _device_batch(x, y)
+    rates = (1e-4, 0.3, 0.1, 0.3)
+
+    def step():
+        tr.forward_backward(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+                            lab.data_ptr(), n, _opts(5, rates, y))
+        torch.cuda.synchronize()
+        return tr.get_grads()
+
+    g0 = step()
+    tr.profile_begin()
+    g1 = step()
+    ms = tr.profile_end()
+    assert len(ms) == 18 and all(0.0 < v < 50.0 for v in ms.values()), ms
+    assert ms["tb_bwd51"] > ms["conv_b_fwd51"]
+    g2 = step()
+    scale = np.abs(g0).max()
+    assert np.abs(g1 - g0).max() < 1e-5 * scale and np.abs(g2 - g0).max() < 1e-5 * scale
+    with pytest.raises(Exception):
+        tr.profile_end()          # nothing armed any more
+    tr.close()
