@@ -296,10 +296,12 @@ __device__ __forceinline__ void dw_unit_t(const float* imgXT, const float* imgYT
         f32x16 acc, prev;
 #pragma unroll
         for (int rg = 0; rg < 16; ++rg) acc[rg] = prev[rg] = 0.f;
+#ifndef DPTM_EXP_NOPREV      // (experiment builds only: prices the read half of the partial-buffer read-modify-write)
         if (sp == 0 && !first) {
 #pragma unroll
             for (int rg = 0; rg < 16; ++rg) prev[rg] = dst[rg * 64];
         }
+#endif
         // operands one group ahead of the four products that use them
         f32x4 ca = *reinterpret_cast<const f32x4*>(ap), cb = *reinterpret_cast<const f32x4*>(bp);
 #pragma unroll 2
@@ -325,7 +327,11 @@ __device__ __forceinline__ void dw_unit_t(const float* imgXT, const float* imgYT
                 for (int rg = 0; rg < 16; ++rg) acc[rg] += xchg[(b * 16 + rg) * 64 + lane];
             }
         }
+#ifdef DPTM_EXP_NOWRITE      // (experiment builds only: no partial-buffer traffic at all but for the last tile's)
+        if (sp == 0 && first) {
+#else
         if (sp == 0) {
+#endif
 #pragma unroll
             for (int rg = 0; rg < 16; ++rg) dst[rg * 64] = acc[rg] + prev[rg];
         }

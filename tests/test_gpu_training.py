@@ -77,6 +77,28 @@ def test_gradients_match_autograd(rates, n):
     tr.close()
 
 
+# batch sizes on both sides of every switch the step makes: 1 row tile / 2 / 4 of the per-site kernels (32|33, 64|65),
+# one-site four-wavefront tiles / one- and two-wavefront tiles (85|86), per-site kernels / layer-wise products (128|129),
+# one-site tiles / larger tiles (191|192); 7 sites: a batch far below one row tile (with 2 sites BatchNorm over two rows amplifies fp32 rounding beyond the bound)
+@pytest.mark.parametrize("n", [7, 33, 65, 85, 86, 129, 192])
+def test_gradients_at_regime_boundaries(n):
+    import torch
+    rates = (1e-4, 0.3, 0.1, 0.3)
+    w = spec.synthetic_weights(11)
+    x = spec.synthetic_inputs(n, 77 + n)
+    y = (np.arange(n) % 3 == 0).astype(np.int64)
+    ref = TrainRef(w)
+    loss_ref, g_ref = ref.step(x, y, lr=5e-4, weight_decay=1e-4, seed=7, rates=dict(zip(("embed", "conv", "tb", "dense"), rates)))
+    tr = _native.Trainer(spec.pack_blob(w), max_batch=max(64, n))
+    d, lab = _device_batch(x, y)
+    loss = tr.forward_backward(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+                               lab.data_ptr(), n, _opts(7, rates, y))
+    torch.cuda.synchronize()
+    assert abs(loss - loss_ref) < 1e-4 * max(1.0, abs(loss_ref)), (loss, loss_ref)
+    _compare_grads(tr.get_grads(), g_ref, f"n={n}")
+    tr.close()
+
+
 def test_two_steps_track_reference():
     import torch
     w = spec.synthetic_weights(101)
