@@ -7,6 +7,7 @@
 #include <memory>
 #include <new>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -635,9 +636,14 @@ int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spe
         hipMemcpy(t->trainable, tr.data(), tr.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(t->G, 0, pb) != hipSuccess || hipMemset(t->M, 0, pb) != hipSuccess || hipMemset(t->V, 0, pb) != hipSuccess)
         return bail(DPTM_EHIP, "dptm_trainer_create: parameter upload");
+    t->arena.cap = arena_bytes(max_batch);
+    if (hipMalloc((void**)&t->arena.base, t->arena.cap) != hipSuccess) return bail(DPTM_ENOMEM, "dptm_trainer_create: activation arena");
+    int rc = alloc_acts(t);
+    if (rc) return rc;
     {
         // per branch: the packed forward image the fused kernels read (layout of dptm_layout.h) and the transposed
-        // images of the backward pass; pack_kernel rebuilds them from W at the start of every step
+        // images of the backward pass; pack_kernel rebuilds them from W at the start of every step.  The same launch
+        // clears what a step accumulates into: the gradient buffer, the loss and the BatchNorm column sums.
         std::vector<PackJob> jobs;
         int64_t off = 0;                       // floats into P
         auto reserve = [&](int64_t floats) {
@@ -694,20 +700,20 @@ int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spe
                 mat(q.c3bk, (int64_t)tap * kD * kD, kBtC3bT + tap * 1024, kD, kD, true, T);
             }
         }
-        if (hipMalloc((void**)&t->P, (size_t)off * sizeof(float)) != hipSuccess ||
-            hipMalloc((void**)&t->pack_jobs, pend.size() * sizeof(PackJob)) != hipSuccess)
-            return bail(DPTM_ENOMEM, "dptm_trainer_create: weight images");
+        if (hipMalloc((void**)&t->P, (size_t)off * sizeof(float)) != hipSuccess) return bail(DPTM_ENOMEM, "dptm_trainer_create: weight images");
         if (hipMemset(t->P, 0, (size_t)off * sizeof(float)) != hipSuccess) return bail(DPTM_EHIP, "dptm_trainer_create: weight images");
         for (const Pending& q : pend)
             jobs.push_back(PackJob{t->W + t->pm.t[q.tensor].off + q.src_off, t->P + q.dst, q.kind, q.K, q.N, q.tr});
+        constexpr int64_t kZeroJob = 65536;        // floats per clearing job
+        for (int64_t at = 0; at < t->pm.total; at += kZeroJob)
+            jobs.push_back(PackJob{nullptr, t->G + at, 3, (int)std::min(kZeroJob, t->pm.total - at), 0, 0});
+        jobs.push_back(PackJob{nullptr, t->d_loss, 3, 64 + 2 * kBnLayers * 1024, 0, 0});   // loss + column sums, back to back
+        if (hipMalloc((void**)&t->pack_jobs, jobs.size() * sizeof(PackJob)) != hipSuccess)
+            return bail(DPTM_ENOMEM, "dptm_trainer_create: weight image table");
         if (hipMemcpy(t->pack_jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice) != hipSuccess)
             return bail(DPTM_EHIP, "dptm_trainer_create: weight image table");
         t->n_pack_jobs = (int)jobs.size();
     }
-    t->arena.cap = arena_bytes(max_batch);
-    if (hipMalloc((void**)&t->arena.base, t->arena.cap) != hipSuccess) return bail(DPTM_ENOMEM, "dptm_trainer_create: activation arena");
-    int rc = alloc_acts(t);
-    if (rc) return rc;
     if (hipDeviceSynchronize() != hipSuccess) return bail(DPTM_EHIP, "dptm_trainer_create: sync");
     *out = owner.release();
     return DPTM_OK;
@@ -744,10 +750,8 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
     const uint8_t* tok[3] = {tok21, tok33, tok51};
     const int64_t B = n;
     int rc;
-    T_TRY(hipMemsetAsync(t->G, 0, (size_t)pm.total * sizeof(float), st));
-    T_TRY(t_pack(t->pack_jobs, t->n_pack_jobs, st));          // weight images of this step's weights
-    // loss accumulator and BatchNorm column sums: allocated back to back (alloc_acts), cleared by one fill
-    T_TRY(hipMemsetAsync(t->d_loss, 0, (size_t)(64 + 2 * kBnLayers * 1024) * sizeof(float), st));
+    // one launch: weight images of this step's weights; gradient buffer, loss accumulator and BatchNorm column sums cleared
+    T_TRY(t_pack(t->pack_jobs, t->n_pack_jobs, st));
     // Small batches without a statistics all-reduce take the per-column kernels of dptm_train_site.hip: one launch per
     // layer and direction instead of a product and half a dozen element-wise passes each.
     const bool small = B <= kSiteMaxRows && !t->ar_fn &&

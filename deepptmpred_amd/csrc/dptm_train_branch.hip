@@ -35,7 +35,7 @@ namespace dptm {
 // ------------------------------------------------------------------------------------ weight images
 
 // kind 0: dst[((t*(K/8) + u)*64 + lane)*4 + e] = M[8u + 4h + e][32t + j], M[k][n] = src[k*N + n] or src[n*K + k]
-// kind 1: dst[(h*(K/8) + u)*4 + e] = src[8u + 4h + e];  kind 2: dst[o] = src[o]
+// kind 1: dst[(h*(K/8) + u)*4 + e] = src[8u + 4h + e];  kind 2: dst[o] = src[o];  kind 3: dst[o] = 0 (o < K)
 __global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ jobs) {
     const PackJob jb = jobs[blockIdx.y];
     if (jb.kind == 0) {
@@ -54,8 +54,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ j
             const int h = g / g8, u = g - h * g8;
             jb.dst[o] = jb.src[8 * u + 4 * h + e];
         }
-    } else {
+    } else if (jb.kind == 2) {
         for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < jb.K; o += gridDim.x * blockDim.x) jb.dst[o] = jb.src[o];
+    } else {
+        for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < jb.K; o += gridDim.x * blockDim.x) jb.dst[o] = 0.f;
     }
 }
 
