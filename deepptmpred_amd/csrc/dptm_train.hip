@@ -704,9 +704,25 @@ int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spe
         if (hipMemset(t->P, 0, (size_t)off * sizeof(float)) != hipSuccess) return bail(DPTM_EHIP, "dptm_trainer_create: weight images");
         for (const Pending& q : pend)
             jobs.push_back(PackJob{t->W + t->pm.t[q.tensor].off + q.src_off, t->P + q.dst, q.kind, q.K, q.N, q.tr});
-        constexpr int64_t kZeroJob = 65536;        // floats per clearing job
-        for (int64_t at = 0; at < t->pm.total; at += kZeroJob)
-            jobs.push_back(PackJob{nullptr, t->G + at, 3, (int)std::min(kZeroJob, t->pm.total - at), 0, 0});
+        // the gradient buffer: 2*lambda*w under the regularised kernels, zero everywhere else (padding included)
+        constexpr int64_t kJobFloats = 65536;
+        auto span = [&](int64_t lo, int64_t hi, bool l2) {
+            for (int64_t at = lo; at < hi; at += kJobFloats)
+                jobs.push_back(PackJob{l2 ? t->W + at : nullptr, t->G + at, l2 ? 4 : 3, (int)std::min(kJobFloats, hi - at), 0, 0});
+        };
+        {
+            std::vector<const Tn*> reg;
+            for (const Tn& x : t->pm.t)
+                if (x.l2) reg.push_back(&x);
+            std::sort(reg.begin(), reg.end(), [](const Tn* a, const Tn* b) { return a->off < b->off; });
+            int64_t cursor = 0;
+            for (const Tn* x : reg) {
+                span(cursor, x->off, false);
+                span(x->off, x->off + x->size, true);
+                cursor = x->off + x->size;
+            }
+            span(cursor, t->pm.total, false);
+        }
         jobs.push_back(PackJob{nullptr, t->d_loss, 3, 64 + 2 * kBnLayers * 1024, 0, 0});   // loss + column sums, back to back
         if (hipMalloc((void**)&t->pack_jobs, jobs.size() * sizeof(PackJob)) != hipSuccess)
             return bail(DPTM_ENOMEM, "dptm_trainer_create: weight image table");
@@ -750,8 +766,10 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
     const uint8_t* tok[3] = {tok21, tok33, tok51};
     const int64_t B = n;
     int rc;
-    // one launch: weight images of this step's weights; gradient buffer, loss accumulator and BatchNorm column sums cleared
-    T_TRY(t_pack(t->pack_jobs, t->n_pack_jobs, st));
+    // one launch: weight images of this step's weights; loss accumulator and BatchNorm column sums cleared; the gradient
+    // buffer cleared, or set to the gradient of the l2 kernel regularisers (model.py:130-138,200,204), whose value
+    // the head / loss kernel adds to the loss
+    T_TRY(t_pack(t->pack_jobs, t->n_pack_jobs, o->l2 > 0.f ? o->l2 * o->l2_scale : 0.f, t->d_step, st));
     // Small batches without a statistics all-reduce take the per-column kernels of dptm_train_site.hip: one launch per
     // layer and direction instead of a product and half a dozen element-wise passes each.
     const bool small = B <= kSiteMaxRows && !t->ar_fn &&
@@ -830,6 +848,8 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
             f.gamma = bn ? c.w(L->bn.gamma) : nullptr; f.mi = mi; f.a = a; f.da = da;
             f.x = x; f.ldx = ldx; f.K = K; f.in_drop = in_drop;
             f.dW = L ? c.g(L->k) : nullptr; f.db = L ? c.g(L->b) : nullptr;
+            f.W = L ? c.w(L->k) : nullptr;
+            f.l2c = L && o->l2 > 0.f && pm.t[L->k].l2 ? 2.0f * o->l2 * o->l2_scale : 0.f;
             f.dgamma = bn ? c.g(L->bn.gamma) : nullptr; f.dbeta = bn ? c.g(L->bn.beta) : nullptr;
             f.N = N; f.B = (int)B; f.step = seed;
             return t_site_bwd(f, ls);
@@ -912,19 +932,6 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
         T_TRY(t_gemm_tn(gt(strct, 8, 0, t->d512a, 128, 0, c.g(pm.strct.k), 128, c.g(pm.strct.b), B, 8, 128), st));
     }
     if ((rc = join(1))) return rc;
-    // l2 kernel regularisers (model.py:130-138,200,204): value into the loss, 2*lambda*w into the gradient
-    if (o->l2 > 0.f) {
-        L2Segs segs;
-        segs.n = 0;
-        for (const Tn& x : pm.t)
-            if (x.l2) {
-                if (segs.n == 16) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward: more than 16 regularised tensors");
-                segs.off[segs.n] = x.off;
-                segs.size[segs.n] = x.size;
-                segs.n += 1;
-            }
-        T_TRY(t_l2(t->W, t->G, segs, o->l2 * o->l2_scale, t->d_loss, st));
-    }
     if (st != caller) {
         T_TRY(hipEventRecord(t->ev_caller[1], st));
         T_TRY(hipStreamWaitEvent(caller, t->ev_caller[1], 0));

@@ -36,7 +36,9 @@ namespace dptm {
 
 // kind 0: dst[((t*(K/8) + u)*64 + lane)*4 + e] = M[8u + 4h + e][32t + j], M[k][n] = src[k*N + n] or src[n*K + k]
 // kind 1: dst[(h*(K/8) + u)*4 + e] = src[8u + 4h + e];  kind 2: dst[o] = src[o];  kind 3: dst[o] = 0 (o < K)
-__global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ jobs) {
+// kind 4: l2 kernel regulariser (model.py:130-138,200,204) of K weights: dst[o] = 2*lambda*src[o] -- the gradient buffer
+//         starts from it, every later writer adds -- and lambda * sum src^2 joins step_params[kStepL2]
+__global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ jobs, float lambda, unsigned* __restrict__ step_params) {
     const PackJob jb = jobs[blockIdx.y];
     if (jb.kind == 0) {
         const int total = jb.K * jb.N;
@@ -56,13 +58,29 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ j
         }
     } else if (jb.kind == 2) {
         for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < jb.K; o += gridDim.x * blockDim.x) jb.dst[o] = jb.src[o];
-    } else {
+    } else if (jb.kind == 3) {
         for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < jb.K; o += gridDim.x * blockDim.x) jb.dst[o] = 0.f;
+    } else {
+        __shared__ float red[4];
+        float s = 0.f;
+        for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < jb.K; o += gridDim.x * blockDim.x) {
+            const float v = jb.src[o];
+            jb.dst[o] = 2.0f * lambda * v;
+            s = fmaf(v, v, s);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float t = (red[0] + red[1]) + (red[2] + red[3]);
+            if (t != 0.f) atomicAdd(reinterpret_cast<float*>(step_params) + kStepL2, lambda * t);
+        }
     }
 }
 
-hipError_t t_pack(const PackJob* jobs_dev, int n_jobs, hipStream_t st) {
-    if (n_jobs) hipLaunchKernelGGL(pack_kernel, dim3(8, (unsigned)n_jobs), dim3(256), 0, st, jobs_dev);
+hipError_t t_pack(const PackJob* jobs_dev, int n_jobs, float lambda, unsigned* step_params, hipStream_t st) {
+    if (n_jobs) hipLaunchKernelGGL(pack_kernel, dim3(8, (unsigned)n_jobs), dim3(256), 0, st, jobs_dev, lambda, step_params);
     return hipGetLastError();
 }
 

@@ -66,7 +66,7 @@ hipError_t t_copy_cols(float* dst, int64_t ldd, int dc, const float* src, int64_
 // Scalars that change every step live in a small device array so that a captured graph of the step can be
 // replayed unchanged: [kStepSeed] dropout seed, [kStepNGlobal] / [kStepNPosGlobal] float bits of the global
 // batch size and positive count of the loss weights.  t_set_step writes them (stream-ordered).
-enum StepParam { kStepSeed = 0, kStepNGlobal = 1, kStepNPosGlobal = 2, kStepParams = 4 };
+enum StepParam { kStepSeed = 0, kStepNGlobal = 1, kStepNPosGlobal = 2, kStepL2 = 3, kStepParams = 4 };
 hipError_t t_set_step(unsigned* step_params, unsigned seed, float n_global, float n_pos_global, hipStream_t st);
 // x = dropout(src ? src : x); with rate 0 and a src this is a plain copy
 hipError_t t_dropout(float* x, int64_t rows, int cols, int64_t ld, int wlen_spatial, const unsigned* step_params, unsigned stream,
@@ -97,12 +97,6 @@ hipError_t t_pool_bwd(const float* x, const float* w, const float* dout, int64_t
                       const float* alpha_save, float* dx, float* dw, float* db, int64_t samples, int wlen, hipStream_t st);
 hipError_t t_head_loss(const float* x, const float* W, const float* bias, const int32_t* labels, int64_t n,
                        const unsigned* step_params, float* proba, float* loss, float* dx, float* dW, float* db, hipStream_t st);
-// l2 kernel regularisers: segments (offset, size) of the flat weight / gradient buffers, all in one launch
-struct L2Segs {
-    int n;
-    int64_t off[16], size[16];
-};
-hipError_t t_l2(const float* w, float* g, const L2Segs& segs, float lambda, float* loss, hipStream_t st);
 hipError_t t_adamw(float* w, const float* g, float* m, float* v, const uint8_t* trainable, float stat_scale, int64_t n,
                    float lr_t, float wd, float b1, float b2, float eps, float gscale, hipStream_t st);
 
@@ -120,7 +114,8 @@ struct PackJob {
     float* dst;
     int kind, K, N, transpose;
 };
-hipError_t t_pack(const PackJob* jobs_dev, int n_jobs, hipStream_t st);
+// lambda: coefficient of the l2 kernel regularisers (kind 4 jobs); step_params[kStepL2] collects lambda * sum w^2
+hipError_t t_pack(const PackJob* jobs_dev, int n_jobs, float lambda, unsigned* step_params, hipStream_t st);
 
 // transposed weight images of one TransformerBlock for the backward kernel, offsets in float4 units
 constexpr int kBtWqT = 0;                    // Wq^T, Wk^T, Wv^T, Wo^T: packed 64 x 64
@@ -326,7 +321,9 @@ struct SiteBwdArgs {
     int64_t ldx;
     int K;
     SiteDrop in_drop;
-    float *dW, *db, *dgamma, *dbeta;   // gradients (raw layouts), added to
+    float *dW, *db, *dgamma, *dbeta;   // gradients (raw layouts): dW is written, the vectors are added to
+    const float* W;          // the layer's own kernel [K][N] and the coefficient of its l2 regulariser:
+    float l2c;               // dW = x^T d(a) + l2c * W (l2c = 0: no regulariser, W is not read)
     int N, B;
     const unsigned* step;
 };

@@ -1062,46 +1062,13 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict_
         if (v != 0.f) atomicAdd(dW + f * 2 + c, v);
     }
     if (threadIdx.x < 3) {
-        const float v = red_s[0][threadIdx.x] + red_s[1][threadIdx.x] + red_s[2][threadIdx.x] + red_s[3][threadIdx.x];
+        float v = red_s[0][threadIdx.x] + red_s[1][threadIdx.x] + red_s[2][threadIdx.x] + red_s[3][threadIdx.x];
+        if (threadIdx.x == 0 && blockIdx.x == 0) v += __uint_as_float(step_params[kStepL2]);   // l2 regularisers (pack_kernel)
         atomicAdd(threadIdx.x == 0 ? loss : db + threadIdx.x - 1, v);
     }
 }
 
 // ------------------------------------------------------------------------------------ optimiser
-
-// l2 kernel regularisers of all regularised tensors in one launch (grid.y = tensor): lambda * sum w^2 into the loss
-// and g += 2*lambda*w.  Segments are offsets into the flat weight / gradient buffers.
-__global__ __launch_bounds__(256) void l2_kernel(const float* __restrict__ w, float* __restrict__ g, L2Segs segs, float lambda,
-                                                  float* __restrict__ loss) {
-    __shared__ float red[4];
-    const int64_t off = segs.off[blockIdx.y], n = segs.size[blockIdx.y];
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    float s = 0.f;
-    // four elements per pass: their loads are in flight together
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += 4 * stride) {
-        float v[4], gv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t j = i + u * stride;
-            v[u] = j < n ? w[off + j] : 0.f;
-            gv[u] = j < n ? g[off + j] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t j = i + u * stride;
-            if (j < n) g[off + j] = fmaf(2.0f * lambda, v[u], gv[u]);
-            s = fmaf(v[u], v[u], s);
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float t = (red[0] + red[1]) + (red[2] + red[3]);
-        if (t != 0.f) atomicAdd(loss, lambda * t);
-    }
-}
 
 // tensorflow-addons AdamW: w -= wd*w, then keras Adam with lr_t = lr*sqrt(1-b2^t)/(1-b1^t).
 // trainable[i] = 0 marks the BatchNorm moving statistics: their slot of the gradient buffer
@@ -1352,14 +1319,11 @@ __global__ void set_step_kernel(unsigned* step_params, unsigned seed, float n_gl
         step_params[kStepSeed] = seed;
         step_params[kStepNGlobal] = __float_as_uint(n_global);
         step_params[kStepNPosGlobal] = __float_as_uint(n_pos_global);
+        step_params[kStepL2] = 0u;       // the step's first launch adds the l2 regularisers' value here
     }
 }
 hipError_t t_set_step(unsigned* step_params, unsigned seed, float n_global, float n_pos_global, hipStream_t st) {
     hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(64), 0, st, step_params, seed, n_global, n_pos_global);
-    return hipGetLastError();
-}
-hipError_t t_l2(const float* w, float* g, const L2Segs& segs, float lambda, float* loss, hipStream_t st) {
-    if (segs.n > 0) hipLaunchKernelGGL(l2_kernel, dim3(96, (unsigned)segs.n), dim3(256), 0, st, w, g, segs, lambda, loss);
     return hipGetLastError();
 }
 hipError_t t_adamw(float* w, const float* g, float* m, float* v, const uint8_t* trainable, float stat_scale, int64_t n,

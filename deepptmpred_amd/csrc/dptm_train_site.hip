@@ -362,7 +362,10 @@ __global__ __launch_bounds__(512) void site_bwd_kernel(SiteBwdArgs p) {
 #pragma unroll
             for (int rg = 0; rg < 16; ++rg) {
                 const int m = 32 * (t + 8 * u) + (rg & 3) + 8 * (rg >> 2) + 4 * hh;
-                if (m < p.K) p.dW[(int64_t)m * p.N + n0 + i] = acc[u][rg];
+                if (m < p.K) {
+                    const int64_t at = (int64_t)m * p.N + n0 + i;
+                    p.dW[at] = p.l2c != 0.f ? fmaf(p.l2c, p.W[at], acc[u][rg]) : acc[u][rg];
+                }
             }
         }
     }
