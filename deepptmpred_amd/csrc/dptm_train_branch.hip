@@ -800,6 +800,7 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
         const int u = item >> 4, o = (item & 15) * 256 + threadIdx.x;
         const int b = o >> 10, rg = (o >> 6) & 15, lane = o & 63;
         const int k = 32 * (b >> 1) + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5), n = 32 * (b & 1) + (lane & 31);
+        if (k >= ut.rows[u]) return;
         src = part + (size_t)u * 4096 + o;
         dst = ut.dst[u] + (size_t)k * ut.ld[u] + n;
     } else {

@@ -175,7 +175,7 @@ __device__ __forceinline__ void bn_swish_backward(const f32x4 (&a)[8], const f32
     }
 }
 
-constexpr int kConvLdsExtra = kXreg + 768;   // exchange buffer (also the per-tile embedding-row sums), coefficient vectors
+constexpr int kConvLdsExtra = kXreg + 768;   // exchange buffer, coefficient vectors
 
 }  // namespace
 
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(512) void conv_b_fwd_kernel(ConvArgs p) {
 // partial buffer of a workgroup (floats): conv_b_bwd: 3 units | conv3b bias gradient;
 // conv_a_bwd: 4 units (conv3a taps, shortcut) | conv3a bias, shortcut bias | embedding rows [21][64] | position rows [W][64]
 constexpr int kCbVec = 3 * 4096;
-constexpr int kCaVec = 4 * 4096, kCaEmb = kCaVec + 128, kCaPos = kCaEmb + kCodes * 64;
+constexpr int kCaVec = 5 * 4096, kCaPos = kCaVec + 128;        // units 0..2 taps, 3 shortcut, 4 embedding table (rows 0..20)
 static_assert(kCaPos + kMaxW * 64 <= kTbPartStride, "the convolution kernels share the TransformerBlock kernel's partial buffer");
 
 // SHORT: the instance for tiles of fewer than eight wavefronts (small batches), see dw_unit
@@ -519,26 +519,27 @@ __global__ __launch_bounds__(512) void conv_a_bwd_kernel(ConvArgs p) {
         }
         dropout_chain(dx0, gsite, h, seed, p.stream_embed, p.thr_embed, p.scale_embed);
         // embedding tables: dP[pos] += rows of every site at that position, dE[code] += rows with that code.
-        // The position rows are summed straight from the image; the code rows meet in LDS (the exchange buffer,
-        // idle here) through atomics.  Both go to the workgroup's partial buffer.
+        // The position rows are summed straight from the image.  The code rows are one more weight-gradient unit:
+        // dE = onehot(code)^T d(x0), with the one-hot rows (32 columns wide, codes 0..20) as the X image.
         chain_store(mine_b, h, dx0);
-        __syncthreads();   // d(x0) of the tile is in image B; the exchange buffer has been read
-        for (int i = tid; i < kCodes * 64; i += blockDim.x) xreg[i] = 0.f;
-        __syncthreads();
+        {
+            int code = row_ok ? (int)p.tok[(site0 + row / W) * W + pos] : -1;
+            code = code > kCodes - 1 ? kCodes - 1 : code;
+            f32x4 oh[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) oh[u][e] = (8 * u + 4 * h + e) == code ? 1.0f : 0.f;
+            chain_store(bufA + row * kLdsStride, h, oh);      // the x0 image has been read by the shortcut's unit
+        }
+        __syncthreads();   // d(x0) and the one-hot rows of the tile are in the images; the exchange buffer has been read
         for (int o = tid; o < W * 64; o += blockDim.x) {
             const int pp = o >> 6, f = o & 63;
             float a = first ? 0.f : part[kCaPos + o];
             for (int s = 0; s < sites_here; ++s) a += bufB[(s * W + pp) * kLdsStride + f];
             part[kCaPos + o] = a;
         }
-        for (int r = wave * 32; r < min(wave * 32 + 32, rows_valid); ++r) {
-            const int s = r / W, pp = r - s * W;
-            int t = p.tok[(site0 + s) * W + pp];
-            t = t > kCodes - 1 ? kCodes - 1 : t;
-            atomicAdd(&xreg[t * 64 + lane], own_b[(r - wave * 32) * kLdsStride + lane]);
-        }
-        __syncthreads();
-        for (int i = tid; i < kCodes * 64; i += blockDim.x) part[kCaEmb + i] = (first ? 0.f : part[kCaEmb + i]) + xreg[i];
+        dw_unit<SHORT>(bufA, bufB, NW, xreg, part + 4 * 4096, first, lane, wave, rows_valid);          // dE += onehot^T d(x0)
         first = false;
     }
     __syncthreads();
@@ -625,18 +626,20 @@ hipError_t t_conv_a_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW,
     const int grid = (int)(a.ntiles < kTbMaxParts ? a.ntiles : kTbMaxParts);
     PartUnits ut;
     PartVecs vt;
-    ut.n = 4;
+    ut.n = 5;
     for (int t = 0; t < 3; ++t) {
         ut.dst[t] = g.c3ak + t * 4096;
         ut.ld[t] = 64;
     }
     ut.dst[3] = g.sck;
     ut.ld[3] = 64;
-    vt.n = 4;
+    ut.dst[4] = g.emb;          // [kCodes][64]: only the unit's first kCodes rows exist
+    ut.ld[4] = 64;
+    ut.rows[4] = kCodes;
+    vt.n = 3;
     vt.dst[0] = g.c3ab; vt.off[0] = kCaVec; vt.len[0] = 64;
     vt.dst[1] = g.scb; vt.off[1] = kCaVec + 64; vt.len[1] = 64;
-    vt.dst[2] = g.emb; vt.off[2] = kCaEmb; vt.len[2] = kCodes * 64;
-    vt.dst[3] = g.pos; vt.off[3] = kCaPos; vt.len[3] = wlen * 64;
+    vt.dst[2] = g.pos; vt.off[2] = kCaPos; vt.len[2] = wlen * 64;
     return t_reduce_parts(a.part, grid, ut, vt, st);
 }
 

@@ -230,6 +230,10 @@ struct PartUnits {
     int n;
     float* dst[24];
     int ld[24];
+    int rows[24];          // rows k >= rows[u] of a unit are dropped (64: the whole unit)
+    PartUnits() : n(0) {
+        for (int i = 0; i < 24; ++i) { dst[i] = nullptr; ld[i] = 64; rows[i] = 64; }
+    }
 };
 struct PartVecs {
     int n;
