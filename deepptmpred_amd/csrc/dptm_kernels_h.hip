@@ -488,11 +488,15 @@ __global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__
                     float tm = st[0];
 #pragma unroll
                     for (int r = 1; r < 16; ++r) tm = fmaxf(tm, st[r]);
-                    const float mn = fmaxf(m, xhalf_max_h(tm));
-                    const float alpha = exp2_h(m - mn);
+                    // the first tile starts the running sums: nothing to rescale (and the first O^T product then takes a
+                    // literal zero as its accumulator instead of sixteen cleared and rescaled registers)
+                    const float mn = bi == 0 ? xhalf_max_h(tm) : fmaxf(m, xhalf_max_h(tm));
+                    if (bi != 0) {
+                        const float alpha = exp2_h(m - mn);
+                        den *= alpha;
+                        ao *= alpha;
+                    }
                     m = mn;
-                    den *= alpha;
-                    ao *= alpha;
                     f32x4 p[4];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
