@@ -146,6 +146,11 @@ int64_t t_tile_rows_max(int64_t max_sites, int wlen) {
     return best;
 }
 
+// What the forward kernel keeps for the backward pass is written once and read once, milliseconds apart: both
+// sides carry the non-temporal hint, so that the arrays do not displace the weight images from the caches.
+__device__ __forceinline__ void keep_store(f32x4* p, const f32x4& v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ f32x4 keep_load(const f32x4* p) { return __builtin_nontemporal_load(p); }
+
 // ------------------------------------------------------------------------------------ forward
 
 template <int W>
@@ -191,13 +196,13 @@ __global__ __launch_bounds__(512) void tb_fwd_kernel(TbFwdArgs p) {
                 gemm_regs<8, 2>(acc, T + kTbWk, x1, lane);
                 acc_to_x<2>(acc, t);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) sv.k[ct + u * 64] = t[u];
+                for (int u = 0; u < 8; ++u) keep_store(&sv.k[ct + u * 64], t[u]);
                 chain_store(mine_a, h, t);
                 acc_init_bias<2>(acc, tv + kVBv * kVec64, h, 8);
                 gemm_regs<8, 2>(acc, T + kTbWv, x1, lane);
                 acc_to_x<2>(acc, t);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) sv.v[ct + u * 64] = t[u];
+                for (int u = 0; u < 8; ++u) keep_store(&sv.v[ct + u * 64], t[u]);
                 chain_store(mine_b, h, t);
             }
             float qh[2][16];
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(512) void tb_fwd_kernel(TbFwdArgs p) {
                 gemm_regs<8, 2>(acc, T + kTbWq, x1, lane);
                 acc_to_x<2>(acc, t);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) sv.q[ct + u * 64] = t[u];
+                for (int u = 0; u < 8; ++u) keep_store(&sv.q[ct + u * 64], t[u]);
                 x_to_heads(t, qh, kQScale);
             }
             __syncthreads();   // K and V of the whole tile are in LDS
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(512) void tb_fwd_kernel(TbFwdArgs p) {
                 sv.stat[cl] = st;
                 heads_to_x(oh, o, 1.0f);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) sv.o[ct + u * 64] = o[u];
+                for (int u = 0; u < 8; ++u) keep_store(&sv.o[ct + u * 64], o[u]);
             }
             // output projection, dropout, residual, LayerNorm 1
             f32x4 hres[8];
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(512) void tb_fwd_kernel(TbFwdArgs p) {
                 for (int u = 0; u < 8; ++u) t[u] += x1[u];
                 iv[0] = ln_normalise(t);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) sv.xh1[ct + u * 64] = t[u];
+                for (int u = 0; u < 8; ++u) keep_store(&sv.xh1[ct + u * 64], t[u]);
                 ln_affine(t, tv + kVLn1G * kVec64, tv + kVLn1B * kVec64, h, hres);
             }
             // FFN 64 -> 256 (swish) -> 64 in four hidden chunks, dropout, residual, LayerNorm 2
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(512) void tb_fwd_kernel(TbFwdArgs p) {
                 for (int u = 0; u < 8; ++u) t[u] += hres[u];
                 iv[1] = ln_normalise(t);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) sv.xh2[ct + u * 64] = t[u];
+                for (int u = 0; u < 8; ++u) keep_store(&sv.xh2[ct + u * 64], t[u]);
                 ln_affine(t, tv + kVLn2G * kVec64, tv + kVLn2B * kVec64, h, x1);
             }
             sv.inv[cl] = iv;
@@ -470,7 +475,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
             const f32x4* pv = p.P + kOffPoolV;
             f32x4 x[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = p.sv[1].xh2[CTL(ct) + u * 64];
+            for (int u = 0; u < 8; ++u) x[u] = keep_load(&p.sv[1].xh2[CTL(ct) + u * 64]);
             ln_affine(x, tv1 + kVLn2G * kVec64, tv1 + kVLn2B * kVec64, h, x);
             const f32x2 pa = p.pool[cl];
             const float* dsite = p.dout + (site0 + row / W) * p.ldd + p.col_off;
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
             {
                 f32x4 xh[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) xh[u] = sv.xh2[CTL(ct) + u * 64];
+                for (int u = 0; u < 8; ++u) xh[u] = keep_load(&sv.xh2[CTL(ct) + u * 64]);
                 ln_backward(dy, xh, iv[1], tv + kVLn2G * kVec64, h, dsum, lane_a, lane_b);
                 wave_fence();
                 atomicAdd(va + kSG2 * 64, colsum32_t(bufA, row0, lane));
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
             {
                 f32x4 xh[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) xh[u] = sv.xh1[CTL(ct) + u * 64];
+                for (int u = 0; u < 8; ++u) xh[u] = keep_load(&sv.xh1[CTL(ct) + u * 64]);
                 ln_affine(xh, tv + kVLn1G * kVec64, tv + kVLn1B * kVec64, h, hx);
             }
             // ---- feed-forward layers backward; the hidden layer is rebuilt in four 64-wide chunks
@@ -599,7 +604,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
                 f32x4 dh[8], xh[8];
                 acc_to_x<2>(acc_dh, dh);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) xh[u] = sv.xh1[CTL(ct) + u * 64];
+                for (int u = 0; u < 8; ++u) xh[u] = keep_load(&sv.xh1[CTL(ct) + u * 64]);
                 ln_backward(dh, xh, iv[0], tv + kVLn1G * kVec64, h, dsum, lane_a, lane_b);
                 wave_fence();
                 atomicAdd(va + kSG1 * 64, colsum32_t(bufA, row0, lane));
@@ -615,7 +620,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     dao[u] = dsum[u];
-                    o[u] = sv.o[CTL(ct) + u * 64];
+                    o[u] = keep_load(&sv.o[CTL(ct) + u * 64]);
                 }
                 dropout_chain(dao, grow, h, seed, p.stream_base + 2 * blk, p.thr, p.scale);
                 chain_store_t(lane_a, o);
@@ -649,14 +654,14 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
                 {
                     f32x4 t[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = sv.k[CTL(ct) + u * 64];
+                    for (int u = 0; u < 8; ++u) t[u] = keep_load(&sv.k[CTL(ct) + u * 64]);
                     chain_store(mine_a, h, t);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = sv.v[CTL(ct) + u * 64];
+                    for (int u = 0; u < 8; ++u) t[u] = keep_load(&sv.v[CTL(ct) + u * 64]);
                     chain_store(mine_b, h, t);
                     float qs[2][16], doh[2][16], gh[2][16];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = sv.q[CTL(ct) + u * 64];
+                    for (int u = 0; u < 8; ++u) t[u] = keep_load(&sv.q[CTL(ct) + u * 64]);
                     x_to_heads(t, qs, kQScale);
                     x_to_heads(dO, doh, 1.0f);
                     TB_SYNC();   // K and V of the tile are in LDS
@@ -677,7 +682,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
                     } else {
                         const f32x4* tv0 = p.P + kOffTb + kTbVec;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) xin[u] = p.sv[0].xh2[CTL(ct) + u * 64];
+                        for (int u = 0; u < 8; ++u) xin[u] = keep_load(&p.sv[0].xh2[CTL(ct) + u * 64]);
                         ln_affine(xin, tv0 + kVLn2G * kVec64, tv0 + kVLn2B * kVec64, h, xin);
                     }
                     chain_store_t(lane_a, xin);
@@ -697,7 +702,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
                 {
                     f32x4 t[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = sv.q[CTL(ct) + u * 64] * kQScale;
+                    for (int u = 0; u < 8; ++u) t[u] = keep_load(&sv.q[CTL(ct) + u * 64]) * kQScale;
                     chain_store(mine_a, h, t);
                     chain_store(mine_b, h, dO);
 #pragma unroll
@@ -708,10 +713,10 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
                     }
                     float kh[2][16], vh[2][16], gk[2][16], gv[2][16];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = sv.k[CTL(ct) + u * 64];
+                    for (int u = 0; u < 8; ++u) t[u] = keep_load(&sv.k[CTL(ct) + u * 64]);
                     x_to_heads(t, kh, 1.0f);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = sv.v[CTL(ct) + u * 64];
+                    for (int u = 0; u < 8; ++u) t[u] = keep_load(&sv.v[CTL(ct) + u * 64]);
                     x_to_heads(t, vh, 1.0f);
                     TB_SYNC();   // scaled Q, dO and the statistics of the tile are in LDS
 #pragma unroll
@@ -733,7 +738,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
                     } else {
                         const f32x4* tv0 = p.P + kOffTb + kTbVec;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) xin[u] = p.sv[0].xh2[CTL(ct) + u * 64];
+                        for (int u = 0; u < 8; ++u) xin[u] = keep_load(&p.sv[0].xh2[CTL(ct) + u * 64]);
                         ln_affine(xin, tv0 + kVLn2G * kVec64, tv0 + kVLn2B * kVec64, h, xin);
                     }
                     chain_store_t(lane_a, xin);
