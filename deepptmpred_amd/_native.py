@@ -33,7 +33,7 @@ EXPORTS = (
     "dptm_trainer_grad_buffer", "dptm_trainer_param_floats", "dptm_trainer_apply",
     "dptm_trainer_get_weights", "dptm_trainer_get_grads", "dptm_trainer_get_proba",
     "dptm_trainer_get_optimizer_state", "dptm_trainer_set_optimizer_state",
-    "dptm_trainer_profile_begin", "dptm_trainer_profile_end",
+    "dptm_trainer_profile_begin", "dptm_trainer_profile_end", "dptm_trainer_loss_buffer",
     "dptm_trainer_last_error", "dptm_trainer_set_allreduce", "dptm_sasa", "dptm_sasa_last_error",
 )
 
@@ -177,6 +177,8 @@ def load_library() -> C.CDLL:
     lib.dptm_trainer_get_optimizer_state.argtypes = [vp, f32p, f32p, C.POINTER(i64)]
     lib.dptm_trainer_set_optimizer_state.restype = C.c_int
     lib.dptm_trainer_set_optimizer_state.argtypes = [vp, f32p, f32p, i64]
+    lib.dptm_trainer_loss_buffer.restype = C.c_int
+    lib.dptm_trainer_loss_buffer.argtypes = [vp, C.POINTER(vp)]
     lib.dptm_trainer_profile_begin.restype = C.c_int
     lib.dptm_trainer_profile_begin.argtypes = [vp]
     lib.dptm_trainer_profile_end.restype = C.c_int
@@ -440,6 +442,12 @@ class Trainer:
             raise err
         _check_t(self._lib, rc, "dptm_trainer_forward_backward")
         return float(loss.value) if want_loss else None
+
+    def loss_buffer(self) -> int:
+        """Device address of the step's loss (one float32, written by forward_backward in stream order)."""
+        p = C.c_void_p()
+        _check_t(self._lib, self._lib.dptm_trainer_loss_buffer(self._h, C.byref(p)), "dptm_trainer_loss_buffer")
+        return int(p.value)
 
     def grad_buffer(self):
         p = C.c_void_p()

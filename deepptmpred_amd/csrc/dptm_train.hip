@@ -737,6 +737,14 @@ int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spe
     return on_texception("dptm_trainer_create");
 }
 
+int dptm_trainer_loss_buffer(dptm_trainer* t, float** dev_ptr) try {
+    if (!t || !dev_ptr) return tfail(DPTM_EINVAL, "dptm_trainer_loss_buffer: NULL argument");
+    *dev_ptr = t->d_loss;
+    return DPTM_OK;
+} catch (...) {
+    return on_texception("dptm_trainer_loss_buffer");
+}
+
 int dptm_trainer_grad_buffer(dptm_trainer* t, float** dev_ptr, int64_t* count) try {
     if (!t || !dev_ptr || !count) return tfail(DPTM_EINVAL, "dptm_trainer_grad_buffer: NULL argument");
     *dev_ptr = t->G;

@@ -231,11 +231,13 @@ class Model:
         trainer = self._trainer(batch_size)
         hist = History()
         lr = trainer.optimizer.learning_rate
+        y_labels = labels_from_targets(y)         # one array for all epochs: the device copy of the data set is kept
         for epoch in range(int(epochs)):
             for cb in cbs:
                 lr = cb.on_epoch_begin(epoch, lr)
             trainer = self._trainer(batch_size)       # a callback may have replaced the weights
-            h1 = trainer.fit(x, y, batch_size, 1, shuffle, lambda _e, _lr, _v=lr: _v, seed=epoch, verbose=0)
+            h1 = trainer.fit(x, y_labels, batch_size, 1, shuffle, lambda _e, _lr, _v=lr: _v, seed=epoch, verbose=0,
+                             keep_resident=True)
             self._dirty = True
             logs = {"loss": h1["loss"][0], "lr": lr}
             if validation_data is not None:
@@ -255,6 +257,8 @@ class Model:
                 cb.on_epoch_end(epoch, logs)
             if any(cb.stop_training for cb in cbs):
                 break
+        if hasattr(trainer.backend, "drop_dataset"):
+            trainer.backend.drop_dataset()
         for cb in cbs:
             cb.on_train_end()
         return hist

@@ -82,6 +82,8 @@ class NativeBackend:
         ptr, count = self.trainer.grad_buffer()
         self._grad_view = self._wrap(ptr, count)
         self._stage = None
+        self._data = None
+        self._data_key = None
         # One stream of its own carries staging copies, forward/backward, the gradient all-reduce and the
         # optimizer update, so they are ordered by the stream and not by host waits.  (A NULL stream handle
         # means "the trainer's private stream" to the library, which RCCL's all-reduce would not be ordered
@@ -97,19 +99,9 @@ class NativeBackend:
     def forward_backward(self, x: Sequence[np.ndarray], labels: np.ndarray, n_global: int, n_pos_global: int,
                          seed: int, rates: DropoutRates, l2: float, l2_scale: float) -> float:
         t = self.torch
-        # fixed staging buffers: a batch always lands at the same device addresses, so the library can replay
-        # its captured launch graph instead of re-issuing ~300 kernels
-        if self._stage is None:
-            mb = self.trainer.max_batch
-            ws = self.spec.window_sizes
-            self._stage = [t.empty((mb, ws[0]), dtype=t.uint8, device=self.device),
-                           t.empty((mb, ws[1]), dtype=t.uint8, device=self.device),
-                           t.empty((mb, ws[2]), dtype=t.uint8, device=self.device),
-                           t.empty((mb, self.spec.struct_feature_dim), dtype=t.float32, device=self.device),
-                           t.empty((mb, self.spec.esm_dim), dtype=t.float32, device=self.device),
-                           t.empty((mb,), dtype=t.int32, device=self.device)]
+        # fixed staging buffers: a batch always lands at the same device addresses
         n = len(labels)
-        d = self._stage
+        d = self._staging()
         o = _native.TrainOpts()
         o.seed = seed & 0xFFFFFFFF
         o.rate_embed, o.rate_conv, o.rate_tb, o.rate_dense = rates.embed, rates.conv, rates.tb, rates.dense
@@ -125,6 +117,65 @@ class NativeBackend:
                                                  d[4].data_ptr(), d[5].data_ptr(), len(labels), o, True,
                                                  self.stream.cuda_stream)
         return loss
+
+    # ---- a data set resident on the device: batches are gathered there and the per-step losses stay there, so a
+    # ---- step needs neither a host-to-device copy nor a wait for the GPU (Keras' fit reports the epoch mean only)
+    RESIDENT_LIMIT_BYTES = 32 << 30
+
+    def set_dataset(self, x: Sequence[np.ndarray], labels: np.ndarray) -> bool:
+        """Uploads the whole training set once (a second call with the same arrays uploads nothing).  False when the
+        set is larger than RESIDENT_LIMIT_BYTES: nothing is uploaded then."""
+        t = self.torch
+        n = len(labels)
+        key = tuple(id(a) for a in x) + (id(labels), n)
+        if self._data is not None and self._data_key == key:
+            return True
+        if n * (sum(self.spec.window_sizes) + 4 * (self.spec.struct_feature_dim + self.spec.esm_dim) + 4) > self.RESIDENT_LIMIT_BYTES:
+            return False
+        with t.cuda.stream(self.stream):
+            data = [t.from_numpy(np.ascontiguousarray(a, dtype=np.uint8)).to(self.device) for a in x[:3]]
+            data += [t.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device) for a in x[3:5]]
+            data.append(t.from_numpy(np.ascontiguousarray(labels, dtype=np.int32)).to(self.device))
+        self._data = data
+        self._data_key = key
+        self._loss_view = self._wrap(self.trainer.loss_buffer(), 1)
+        return True
+
+    def drop_dataset(self) -> None:
+        self._data = None
+        self._data_key = None
+
+    def _staging(self):
+        t = self.torch
+        if self._stage is None:
+            mb = self.trainer.max_batch
+            ws = self.spec.window_sizes
+            self._stage = [t.empty((mb, ws[0]), dtype=t.uint8, device=self.device),
+                           t.empty((mb, ws[1]), dtype=t.uint8, device=self.device),
+                           t.empty((mb, ws[2]), dtype=t.uint8, device=self.device),
+                           t.empty((mb, self.spec.struct_feature_dim), dtype=t.float32, device=self.device),
+                           t.empty((mb, self.spec.esm_dim), dtype=t.float32, device=self.device),
+                           t.empty((mb,), dtype=t.int32, device=self.device)]
+        return self._stage
+
+    def forward_backward_resident(self, idx_dev, n_global: int, n_pos_global: int, seed: int, rates: DropoutRates,
+                                  l2: float, l2_scale: float, loss_out) -> None:
+        """One step on the rows ``idx_dev`` (device int64 tensor) of the resident data set; the step's loss is copied
+        to the one-element device tensor ``loss_out``.  Nothing here waits for the GPU."""
+        t = self.torch
+        d = self._staging()
+        n = int(idx_dev.numel())
+        o = _native.TrainOpts()
+        o.seed = seed & 0xFFFFFFFF
+        o.rate_embed, o.rate_conv, o.rate_tb, o.rate_dense = rates.embed, rates.conv, rates.tb, rates.dense
+        o.n_global, o.n_pos_global = int(n_global), int(n_pos_global)
+        o.l2, o.l2_scale = l2, l2_scale
+        with t.cuda.stream(self.stream):
+            for buf, a in zip(d, self._data):
+                t.index_select(a, 0, idx_dev, out=buf[:n])
+            self.trainer.forward_backward(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
+                                          d[4].data_ptr(), d[5].data_ptr(), n, o, False, self.stream.cuda_stream)
+            loss_out.copy_(self._loss_view, non_blocking=True)
 
     def enable_sync_batchnorm(self, group=None) -> None:
         """Every BatchNorm then normalises with the statistics of the GLOBAL batch: its column sums are
@@ -228,18 +279,39 @@ class DataParallelTrainer:
         return loss
 
     def fit(self, x: Sequence[np.ndarray], y, batch_size: int = 64, epochs: int = 1, shuffle: bool = True,
-            lr_scheduler: Optional[Callable[[int, float], float]] = None, seed: int = 0, verbose: int = 0) -> Dict[str, List[float]]:
+            lr_scheduler: Optional[Callable[[int, float], float]] = None, seed: int = 0, verbose: int = 0,
+            keep_resident: bool = False) -> Dict[str, List[float]]:
         """``model.fit`` loop (trainer.py:332-339) without the reference's callbacks other
         than the learning-rate schedule."""
-        labels = labels_from_targets(y)
+        labels = y if isinstance(y, np.ndarray) and y.ndim == 1 and y.dtype == np.int32 else labels_from_targets(y)
         n = len(labels)
         lr = self.optimizer.learning_rate
         hist: Dict[str, List[float]] = {"loss": [], "lr": []}
         rng = np.random.default_rng(seed)
+        # one process: the data set goes to the device once, batches are gathered there, and the per-step losses are
+        # read once per epoch; same batches, seeds and arithmetic as the train_on_batch loop below
+        resident = self._dist()[2] == 1 and hasattr(self.backend, "set_dataset") and self.backend.set_dataset(x, labels)
         for ep in range(epochs):
             if lr_scheduler is not None:
                 lr = float(lr_scheduler(ep, lr))
             order = rng.permutation(n) if shuffle else np.arange(n)
+            if resident:
+                torch = self.backend.torch
+                order_dev = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int64)).to(self.backend.device)
+                starts = list(range(0, n, batch_size))
+                losses_dev = torch.zeros(len(starts), dtype=torch.float32, device=self.backend.device)
+                for k, s in enumerate(starts):
+                    idx = order[s:s + batch_size]
+                    self.backend.forward_backward_resident(order_dev[s:s + len(idx)], len(idx), int(labels[idx].sum()),
+                                                           self.steps * 1000003, self.rates, self.l2, 1.0, losses_dev[k:k + 1])
+                    self.backend.apply(lr, self.optimizer.weight_decay, 1.0)
+                    self.steps += 1
+                with torch.cuda.stream(self.backend.stream):
+                    hist["loss"].append(float(losses_dev.double().mean().cpu()))
+                hist["lr"].append(lr)
+                if verbose:
+                    print(f"epoch {ep + 1}/{epochs} - loss {hist['loss'][-1]:.4f} - lr {lr:.2e}")
+                continue
             losses = []
             for s in range(0, n, batch_size):
                 idx = order[s:s + batch_size]
@@ -248,4 +320,6 @@ class DataParallelTrainer:
             hist["lr"].append(lr)
             if verbose:
                 print(f"epoch {ep + 1}/{epochs} - loss {hist['loss'][-1]:.4f} - lr {lr:.2e}")
+        if resident and not keep_resident:      # (keep_resident: the caller's next fit call passes the same arrays)
+            self.backend.drop_dataset()
         return hist

@@ -294,6 +294,12 @@ int dptm_trainer_get_proba(dptm_trainer* t, float* host_out, int64_t n);
  * model.fit (pred/train_PTM/trainer.py:304-309, 332-339). */
 int dptm_trainer_get_optimizer_state(dptm_trainer* t, float* m_host_out, float* v_host_out, int64_t* step_out);
 int dptm_trainer_set_optimizer_state(dptm_trainer* t, const float* m_host, const float* v_host, int64_t step);
+/* Device address of the step's loss: one float that dptm_trainer_forward_backward writes in stream order (data
+ * term + l2 regularisers, what loss_out receives).  A training loop that copies it device-to-device after every
+ * step and reads the copies once per epoch need not wait for the GPU at every step, as Keras' model.fit does not
+ * (pred/train_PTM/trainer.py:332-339: the per-batch losses only surface as the epoch's mean). */
+int dptm_trainer_loss_buffer(dptm_trainer* t, float** dev_ptr);
+
 /* Per-kernel clocks of one training step, the trainer's counterpart of dptm_profile_begin / _end (the
  * reference has none; Keras' own tooling would be the TensorBoard profiler callback).  Between _begin and
  * _end the three sequence branches run one after another on one stream and each of their six launches is

@@ -288,3 +288,31 @@ def test_trainer_profile_times_the_branch_launches():
     with pytest.raises(Exception):
         tr.profile_end()          # nothing armed any more
     tr.close()
+
+
+def test_fit_with_the_data_set_on_the_device_equals_the_host_loop():
+    """Model.fit keeps the training set on the device (batches gathered there, losses read once per epoch); the
+    batches, seeds and arithmetic are those of the train_on_batch loop over host arrays."""
+    from deepptmpred_amd import create_ptm_model
+    from deepptmpred_amd.training import AdamW, NativeBackend
+    n, b = 200, 64
+    x = spec.synthetic_inputs(n, 5)
+    y = (np.random.default_rng(3).random(n) < 0.3).astype(np.int64)
+    runs = []
+    for resident in (True, False):
+        m = create_ptm_model(None, seed=2)
+        m.compile(optimizer=AdamW(learning_rate=5e-4, weight_decay=1e-4))
+        if not resident:
+            orig = NativeBackend.set_dataset
+            NativeBackend.set_dataset = lambda self, x_, l_: False
+        try:
+            h = m.fit(x, y, batch_size=b, epochs=2, verbose=0)
+        finally:
+            if not resident:
+                NativeBackend.set_dataset = orig
+        runs.append((h.history["loss"], m.get_weights()))
+        m.close()
+    (la, wa), (lb, wb) = runs
+    assert np.allclose(la, lb, rtol=2e-4), (la, lb)
+    for a, c in zip(wa, wb):
+        assert np.abs(a - c).max() < 2e-4 * max(1.0, np.abs(c).max())
