@@ -24,7 +24,7 @@ Also reported on the same line (N = 1):
   proteome     many small proteins per call through dptm_score_proteins_device: window
                assembly + ESM row gather on the device (BASELINE north_star 1 and 4).
   sweep        BASELINE config 4 on one GPU: 17 weight sets over 262,144 resident sites.
-  train        BASELINE config 5 on one GPU: training step at batch 64 and 8192.
+  train        BASELINE config 5 on one GPU: training step at batch 64 and 8192, and the Model.fit loop around it.
 Other modes (`--types T`, `--train`, `--proteome`) print their own single line and shard over
 ranks the same way.
 """
@@ -345,6 +345,26 @@ def measure_train(R: Ranks, batch: int, steps: int, warmup: int) -> dict:
             "kernel_ms_serial_total": round(sum(kernel_ms.values()), 4)}
 
 
+def measure_fit(R: Ranks, sites: int = 6400, batch: int = 64) -> dict:
+    """Wall time per step of the Keras-style loop (Model.fit on host arrays, trainer.py:332-339): the training set is
+    uploaded once, batches are gathered on the device, losses are read once per epoch."""
+    from deepptmpred_amd import create_ptm_model, spec
+    from deepptmpred_amd.training import AdamW
+    x = spec.synthetic_inputs(sites, 3)
+    y = (np.random.default_rng(1).random(sites) < 0.042).astype(np.int64)
+    m = create_ptm_model(None, device=R.local)
+    m.compile(optimizer=AdamW(learning_rate=5e-4, weight_decay=1e-4))
+    m.fit(x, y, batch_size=batch, epochs=1, verbose=0)          # warm-up epoch
+    t0 = time.perf_counter()
+    h = m.fit(x, y, batch_size=batch, epochs=2, verbose=0)
+    dt = time.perf_counter() - t0
+    steps = 2 * ((sites + batch - 1) // batch)
+    m.close()
+    assert np.isfinite(h.history["loss"]).all()
+    return {"batch": batch, "steps": steps, "ms_per_step_wall": dt / steps * 1e3, "sites_per_s": 2 * sites / dt,
+            "note": "Model.fit, host arrays in: data set resident on the device, losses read once per epoch"}
+
+
 def train_main(args, R: Ranks) -> None:
     m = measure_train(R, args.batch, args.steps, args.warmup)
     if R.rank == 0:
@@ -657,7 +677,8 @@ def main() -> None:
         del x, xs, out
         torch.cuda.empty_cache()
         extras["train"] = {"batch64": measure_train(R, 64, 50, 10),
-                           "batch8192": measure_train(R, 8192, 5, 2) if n >= 262144 else None}
+                           "batch8192": measure_train(R, 8192, 5, 2) if n >= 262144 else None,
+                           "fit_batch64": measure_fit(R, 6400 if n >= 262144 else 640)}
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
