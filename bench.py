@@ -297,7 +297,8 @@ def measure_train(R: Ranks, batch: int, steps: int, warmup: int) -> dict:
     o.n_global, o.n_pos_global, o.l2, o.l2_scale = batch * world, n_pos, 1e-4, 1.0 / world
     # one explicit stream for the whole step: the library's kernels, RCCL's all-reduce (which orders itself
     # after torch's current stream) and the optimizer update are then stream-ordered without host syncs
-    tstream = torch.cuda.Stream(device=dev)
+    # -- the trainer's own main stream, so that the step starts and ends without a hand-over between streams
+    tstream = backend.stream
     st = tstream.cuda_stream
     torch.cuda.synchronize()
 

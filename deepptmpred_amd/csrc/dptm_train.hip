@@ -745,6 +745,14 @@ int dptm_trainer_loss_buffer(dptm_trainer* t, float** dev_ptr) try {
     return on_texception("dptm_trainer_loss_buffer");
 }
 
+int dptm_trainer_stream(dptm_trainer* t, void** stream) try {
+    if (!t || !stream) return tfail(DPTM_EINVAL, "dptm_trainer_stream: NULL argument");
+    *stream = (void*)t->stream;
+    return DPTM_OK;
+} catch (...) {
+    return on_texception("dptm_trainer_stream");
+}
+
 int dptm_trainer_grad_buffer(dptm_trainer* t, float** dev_ptr, int64_t* count) try {
     if (!t || !dev_ptr || !count) return tfail(DPTM_EINVAL, "dptm_trainer_grad_buffer: NULL argument");
     *dev_ptr = t->G;

@@ -84,11 +84,11 @@ class NativeBackend:
         self._stage = None
         self._data = None
         self._data_key = None
-        # One stream of its own carries staging copies, forward/backward, the gradient all-reduce and the
-        # optimizer update, so they are ordered by the stream and not by host waits.  (A NULL stream handle
-        # means "the trainer's private stream" to the library, which RCCL's all-reduce would not be ordered
-        # against: the handle passed down is therefore never 0.)
-        self.stream = torch.cuda.Stream(device=self.device)
+        # ONE stream carries staging copies, forward/backward, the gradient all-reduce and the optimizer update, so
+        # they are ordered by the stream and not by host waits: the trainer's own main stream, seen by torch as an
+        # external stream.  The step then starts and ends without a hand-over between streams, and the process has
+        # no further busy stream to share a hardware queue with one of the step's four.
+        self.stream = torch.cuda.ExternalStream(self.trainer.stream(), device=self.device)
 
     def _wrap(self, ptr: int, count: int):
         """torch view of library-owned device memory (for the RCCL all-reduce)."""

@@ -300,6 +300,14 @@ int dptm_trainer_set_optimizer_state(dptm_trainer* t, const float* m_host, const
  * (pred/train_PTM/trainer.py:332-339: the per-batch losses only surface as the epoch's mean). */
 int dptm_trainer_loss_buffer(dptm_trainer* t, float** dev_ptr);
 
+/* The stream the step's main lane runs on (a hipStream_t the trainer owns; it dies with the trainer).  The step
+ * always runs on the trainer's own streams, one per hardware queue of the process; a call made on another stream
+ * hands over to them and back through two events.  A training loop that enqueues its own work -- batch staging,
+ * the gradient all-reduce, dptm_trainer_apply -- on THIS stream and passes it as `stream` has no hand-over, and no
+ * further busy stream that shares a hardware queue with one of the step's.  No counterpart in the reference
+ * (TensorFlow owns its streams). */
+int dptm_trainer_stream(dptm_trainer* t, void** stream);
+
 /* Per-kernel clocks of one training step, the trainer's counterpart of dptm_profile_begin / _end (the
  * reference has none; Keras' own tooling would be the TensorBoard profiler callback).  Between _begin and
  * _end the three sequence branches run one after another on one stream and each of their six launches is

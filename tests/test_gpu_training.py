@@ -290,6 +290,43 @@ def test_trainer_profile_times_the_branch_launches():
     tr.close()
 
 
+def test_step_on_the_trainers_own_stream_equals_a_step_on_any_other():
+    """dptm_trainer_stream: the stream of the step's main lane.  A step enqueued on it (no hand-over between streams)
+    gives what a step enqueued on torch's current stream or on the NULL stream gives, inputs staged on that stream
+    included."""
+    import torch
+    n = 70
+    w = spec.synthetic_weights(4)
+    x = spec.synthetic_inputs(n, 13)
+    y = (np.random.default_rng(8).random(n) < 0.3).astype(np.int64)
+    tr = _native.Trainer(spec.pack_blob(w), max_batch=128)
+    handle = tr.stream()
+    assert handle != 0
+    own = torch.cuda.ExternalStream(handle, device=torch.device("cuda:0"))
+    rates = (1e-4, 0.3, 0.1, 0.3)
+    d, lab = _device_batch(x, y)
+    torch.cuda.synchronize()
+    grads = []
+    for stream in (None, torch.cuda.current_stream(), own):
+        if stream is None:
+            args, sh = (d, lab), 0
+        else:
+            with torch.cuda.stream(stream):        # staging copies ordered by the same stream as the step
+                args = ([a.clone() for a in d], lab.clone())
+            sh = stream.cuda_stream
+        a, l = args
+        tr.forward_backward(a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), a[4].data_ptr(),
+                            l.data_ptr(), n, _opts(21, rates, y), False, sh)
+        tr.apply(0.0, 0.0, 1.0, 0.0, sh)       # learning rate 0 and no decay: the weights stay
+        torch.cuda.synchronize()
+        grads.append(tr.get_grads())
+    scale = np.abs(grads[0]).max()
+    assert scale > 0
+    for g in grads[1:]:
+        assert np.abs(g - grads[0]).max() < 1e-5 * scale
+    tr.close()
+
+
 def test_fit_with_the_data_set_on_the_device_equals_the_host_loop():
     """Model.fit keeps the training set on the device (batches gathered there, losses read once per epoch); the
     batches, seeds and arithmetic are those of the train_on_batch loop over host arrays."""
