@@ -55,7 +55,7 @@ struct AssembleArgs {
     uint8_t* t33;                  // [n][33]
     uint8_t* t51;                  // [n][51]
     int32_t* esm_row;              // [n] table row of the site, or -1 (zero row)
-    bool words;                    // set by launch_assemble
+    bool words;                    // set by launch_assemble: every output array is 16-byte aligned
 };
 hipError_t launch_assemble(const AssembleArgs& a, hipStream_t st);
 hipError_t prepare_kernels();

@@ -563,62 +563,36 @@ __global__ __launch_bounds__(512) void dense_small_kernel(DenseArgs p) {
 // Window assembly (predict.py:529-560) and the ESM row index (predict.py:487-501) for sites of many
 // proteins at once: column c of the W-window of 1-based, protein-local position `pos` is residue
 // pos-1-(W-1)/2+c of that protein, or the padding code 20 outside 0..L-1 (also for codes > 20).
-// A workgroup owns kAsmSites consecutive sites: their (sequence base, length, position) go to LDS once,
-// then the three output ranges [s0*W, (s0+kAsmSites)*W) -- contiguous bytes -- are produced one 32-bit
-// word per thread, so a wavefront's stores are 256 contiguous bytes; the residue bytes come through the
-// vector cache (neighbouring sites of a protein share most of their windows).  64 sites per workgroup
-// keep a 32,768-site pass at 512 workgroups (two per CU) with ~7 words per thread.
+// A workgroup owns kAsmSites consecutive sites, whose three output ranges [s0*W, (s0+kAsmSites)*W) are
+// contiguous bytes.  The W=33 and W=21 windows of a site are the middle of its W=51 window, so every residue
+// byte is fetched and clamped ONCE (four threads per site, through the vector cache: neighbouring sites of a
+// protein share most of their windows) and dropped into up to three LDS images that hold the tile's output
+// bytes in output order; the images then leave as 16-byte stores, 1 KiB per wavefront instruction.
 // seq_off == nullptr: one protein of length a.L (site_protein is then not read).
 // ------------------------------------------------------------------------------------
 constexpr int kAsmSites = 64;
+constexpr int kAsmImg21 = 0, kAsmImg33 = kAsmSites * 21, kAsmImg51 = kAsmImg33 + kAsmSites * 33;   // byte offsets
+constexpr int kAsmImgBytes = kAsmSites * (21 + 33 + 51);
+static_assert(kAsmImg33 % 16 == 0 && kAsmImg51 % 16 == 0 && kAsmImgBytes % 16 == 0, "images start on 16-byte boundaries");
 
-template <int W>
-__device__ __forceinline__ void assemble_window(const AssembleArgs& a, uint8_t* __restrict__ dst, int64_t s0, int rows,
-                                                const int64_t* s_base, const int32_t* s_len, const int32_t* s_pos0,
-                                                bool words) {
-    constexpr int half = (W - 1) / 2;
-    const int bytes = rows * W;
-    uint8_t* out = dst + s0 * W;
-    for (int d = threadIdx.x; 4 * d < bytes; d += blockDim.x) {
-        int sl = (4 * d) / W;
-        int c = 4 * d - sl * W;
-        uint32_t v = 0;
-        uint8_t b4[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            uint8_t code = 20;
-            if (4 * d + b < bytes) {
-                const int i = s_pos0[sl] - half + c;
-                if (i >= 0 && i < s_len[sl]) {
-                    code = a.codes[s_base[sl] + i];
-                    code = code > 20 ? 20 : code;
-                }
-            }
-            b4[b] = code;
-            v |= (uint32_t)code << (8 * b);
-            if (++c == W) { c = 0; ++sl; }
-        }
-        if (words && 4 * d + 3 < bytes) {
-            *reinterpret_cast<uint32_t*>(out + 4 * d) = v;
-        } else {
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-                if (4 * d + b < bytes) out[4 * d + b] = b4[b];
-        }
-    }
+// bytes [0, bytes) of an LDS image to `out`; vec: `out` is 16-byte aligned
+__device__ __forceinline__ void assemble_flush(const uint8_t* img, uint8_t* __restrict__ out, int bytes, bool vec) {
+    const int whole = vec ? bytes >> 4 : 0;
+    for (int d = threadIdx.x; d < whole; d += blockDim.x)
+        reinterpret_cast<uint4*>(out)[d] = reinterpret_cast<const uint4*>(img)[d];
+    for (int o = 16 * whole + threadIdx.x; o < bytes; o += blockDim.x) out[o] = img[o];
 }
 
 __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
-    __shared__ int64_t s_base[kAsmSites];
-    __shared__ int32_t s_len[kAsmSites];
-    __shared__ int32_t s_pos0[kAsmSites];
+    __shared__ __attribute__((aligned(16))) uint8_t img[kAsmImgBytes + 256];   // + a spare byte per thread
     const int tid = threadIdx.x;
+    const int sl = tid >> 2, q = tid & 3;          // four threads per site; thread q takes columns 13q .. 13q+12 of W=51
     const int64_t tiles = (a.n + kAsmSites - 1) / kAsmSites;
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int64_t s0 = tile * kAsmSites;
         const int rows = (int)min((int64_t)kAsmSites, a.n - s0);
-        if (tid < rows) {
-            const int64_t site = s0 + tid;
+        if (sl < rows) {
+            const int64_t site = s0 + sl;
             const int32_t pos = a.positions[site];
             int64_t base = 0, len = a.L, erow0 = 0, erows = a.esm_rows;
             if (a.seq_off) {
@@ -628,15 +602,34 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
                 erow0 = a.esm_off[p];
                 erows = a.esm_off[p + 1] - erow0;
             }
-            s_base[tid] = base;
-            s_len[tid] = (int32_t)len;
-            s_pos0[tid] = pos - 1;
-            a.esm_row[site] = (pos - 1 < erows) ? (int32_t)(erow0 + pos - 1) : -1;
+            if (q == 0) a.esm_row[site] = (pos - 1 < erows) ? (int32_t)(erow0 + pos - 1) : -1;
+            const int i0 = pos - 1 - 25;
+            const uint8_t* src = a.codes + base;
+            // every residue byte of the thread is requested before the first is used: the loads are unconditional
+            // (index clamped into the protein, which holds at least the site's own residue), the padding code is
+            // chosen afterwards, and a byte that a window does not hold goes to a spare byte of the thread's own
+            // instead of round a branch
+            const int last = (int)len - 1;
+            uint8_t code[13];
+#pragma unroll
+            for (int k = 0; k < 13; ++k) {
+                const int i = i0 + 13 * q + k;
+                code[k] = src[i < 0 ? 0 : (i > last ? last : i)];
+            }
+            const int spare = kAsmImgBytes + tid;
+#pragma unroll
+            for (int k = 0; k < 13; ++k) {
+                const int c = 13 * q + k, i = i0 + c;
+                const uint8_t v = (i < 0 || i > last || code[k] > 20) ? (uint8_t)20 : code[k];
+                img[c < 51 ? kAsmImg51 + sl * 51 + c : spare] = v;
+                img[(c >= 9 && c < 42) ? kAsmImg33 + sl * 33 + c - 9 : spare] = v;
+                img[(c >= 15 && c < 36) ? kAsmImg21 + sl * 21 + c - 15 : spare] = v;
+            }
         }
         __syncthreads();
-        assemble_window<21>(a, a.t21, s0, rows, s_base, s_len, s_pos0, a.words);
-        assemble_window<33>(a, a.t33, s0, rows, s_base, s_len, s_pos0, a.words);
-        assemble_window<51>(a, a.t51, s0, rows, s_base, s_len, s_pos0, a.words);
+        assemble_flush(img + kAsmImg21, a.t21 + s0 * 21, rows * 21, a.words);
+        assemble_flush(img + kAsmImg33, a.t33 + s0 * 33, rows * 33, a.words);
+        assemble_flush(img + kAsmImg51, a.t51 + s0 * 51, rows * 51, a.words);
         __syncthreads();
     }
 }
@@ -716,10 +709,10 @@ hipError_t launch_assemble(const AssembleArgs& a, hipStream_t st) {
     int64_t blocks = (a.n + kAsmSites - 1) / kAsmSites;
     if (blocks > 256 * 32) blocks = 256 * 32;
     AssembleArgs k = a;
-    // whole 32-bit words can be stored when every output array starts on a 4-byte boundary (a tile's byte
-    // range starts at a multiple of 64*W)
+    // 16-byte stores when every output array starts on a 16-byte boundary (a tile's byte range starts at a
+    // multiple of 64*W); single bytes otherwise
     k.words = ((reinterpret_cast<uintptr_t>(a.t21) | reinterpret_cast<uintptr_t>(a.t33) |
-                reinterpret_cast<uintptr_t>(a.t51)) & 3) == 0;
+                reinterpret_cast<uintptr_t>(a.t51)) & 15) == 0;
     hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)blocks), dim3(256), 0, st, k);
     return hipGetLastError();
 }

@@ -140,11 +140,11 @@ def test_large_batch_matches_device_form_and_assembled_inputs(model, weights):
     assert np.abs(host[k] - ref).max() < TOL
 
 
-@pytest.mark.parametrize("byte_offset", [0, 1])
+@pytest.mark.parametrize("byte_offset", [0, 1, 4])
 def test_assemble_proteins_bit_exact(model, byte_offset):
     """Every residue of 40 proteins (lengths 1..300) as a site: windows equal the reference's string code
     (predict.py:529-560) byte for byte and the row index follows predict.py:493; also with output arrays
-    that start off a 4-byte boundary (byte stores instead of word stores)."""
+    that start off a 16-byte boundary (byte stores instead of 16-byte stores)."""
     import torch
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(9)
