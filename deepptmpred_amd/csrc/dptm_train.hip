@@ -327,6 +327,14 @@ struct ProfScope {
     }
 };
 
+// Tile counter of backward launch k (0: TransformerBlocks, 1: second convolution, 2: first convolution) of branch b.
+// The counters sit in the unused part of the 64-float loss slot, which the step's first launch clears together with
+// the BatchNorm column sums.
+// A launch with a workgroup per tile needs none (nullptr: tiles by workgroup index).
+unsigned* tile_queue(dptm_trainer* t, int b, int k, int64_t ntiles) {
+    return ntiles > kTbMaxParts ? reinterpret_cast<unsigned*>(t->d_loss + 32) + b * 3 + k : nullptr;
+}
+
 // per-branch arguments shared by the four convolution-block kernels
 ConvArgs conv_args(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigned* seed, const Rates& rt, const TileCfg& tc) {
     dptm_trainer* t = c.t;
@@ -353,6 +361,8 @@ ConvArgs conv_args(const Ctx& c, int b, const uint8_t* tok, int64_t B, const uns
     f.dx1 = c.s->dx1;
     f.dz1 = c.s->dz1;
     f.part = c.s->part;
+    f.queue_b = tile_queue(t, b, 1, tc.ntiles);
+    f.queue_a = tile_queue(t, b, 2, tc.ntiles);
     f.n_sites = B;
     f.S = tc.S;
     f.ntiles = tc.ntiles;
@@ -442,6 +452,7 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
         f.col_off = b * 64;
         f.dx1 = c.s->dx1;
         f.part = c.s->part;
+        f.queue = tile_queue(t, b, 0, tc.ntiles);
         f.n_sites = B;
         f.S = tc.S;
         f.ntiles = tc.ntiles;

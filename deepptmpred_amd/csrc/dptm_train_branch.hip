@@ -457,9 +457,13 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
     bn_prepare(p.bn2, bnv, tid, false);
     __syncthreads();
     bool first = true;
+    // (the eight-wavefront tile uses every byte of LDS a workgroup can have: the tile slot lives in the unused part of
+    // the pooling-bias slot of the column sums, of which only the first float is ever summed)
+    int* tile_slot = reinterpret_cast<int*>(vacc + kSPoolB * 64 + 32);
+    int tile_round = 0;
     PH_DECL
 #pragma unroll 1
-    for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    for (int64_t tile = next_tile(p.queue, tile_slot, tile_round); tile < p.ntiles; tile = next_tile(p.queue, tile_slot, tile_round)) {
         const int64_t site0 = tile * S;
         const int sites_here = (int)min((int64_t)S, p.n_sites - site0);
         const int rows_valid = sites_here * W;
@@ -779,6 +783,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
         first = false;
     }
     __syncthreads();
+    if (first) zero_floats(part, kTbUnits * 4096);
     for (int i = tid; i < kTbVecs * 64; i += blockDim.x) {
         const int slot = i >> 6;
         if (slot == kSBn2A)

@@ -362,8 +362,10 @@ __global__ __launch_bounds__(512) void conv_b_bwd_kernel(ConvArgs p) {
         bn_prepare(f, bnv, tid, false);
     }
     bool first = true;
+    int tile_round = 0;
+    __shared__ int tile_slot;
 #pragma unroll 1
-    for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    for (int64_t tile = next_tile(p.queue_b, &tile_slot, tile_round); tile < p.ntiles; tile = next_tile(p.queue_b, &tile_slot, tile_round)) {
         const int64_t site0 = tile * S;
         const int sites_here = (int)min((int64_t)S, p.n_sites - site0);
         const int rows_valid = sites_here * W;
@@ -437,6 +439,7 @@ __global__ __launch_bounds__(512) void conv_b_bwd_kernel(ConvArgs p) {
         first = false;
     }
     __syncthreads();
+    if (first) zero_floats(part, 3 * 4096);
     for (int i = tid; i < 192; i += blockDim.x) {
         if (i < 64)
             part[kCbVec + i] = vacc[i];
@@ -465,8 +468,10 @@ __global__ __launch_bounds__(512) void conv_a_bwd_kernel(ConvArgs p) {
     for (int i = tid; i < 128; i += blockDim.x) vacc[i] = 0.f;
     bn_bwd_prepare(p.bb1, bb, tid, blockIdx.x == 0);
     bool first = true;
+    int tile_round = 0;
+    __shared__ int tile_slot;
 #pragma unroll 1
-    for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    for (int64_t tile = next_tile(p.queue_a, &tile_slot, tile_round); tile < p.ntiles; tile = next_tile(p.queue_a, &tile_slot, tile_round)) {
         const int64_t site0 = tile * S;
         const int sites_here = (int)min((int64_t)S, p.n_sites - site0);
         const int rows_valid = sites_here * W;
@@ -543,6 +548,10 @@ __global__ __launch_bounds__(512) void conv_a_bwd_kernel(ConvArgs p) {
         first = false;
     }
     __syncthreads();
+    if (first) {
+        zero_floats(part, 5 * 4096);
+        zero_floats(part + kCaPos, W * 64);
+    }
     for (int i = tid; i < 128; i += blockDim.x) part[kCaVec + i] = vacc[i];
 }
 

@@ -208,6 +208,7 @@ struct TbBwdArgs {
     int col_off;
     f32x4_tr* dx1;         // gradient w.r.t. x1, chain-tiled
     float* part;           // [grid][kTbPartStride]
+    unsigned* queue;       // tile counter of this launch, zero when the launch starts (see next_tile)
     int64_t n_sites;
     int S;
     int64_t ntiles;
@@ -262,6 +263,7 @@ struct ConvArgs {
     const f32x4_tr* dx1;       // from the TransformerBlock backward kernel
     f32x4_tr* dz1;             // gradient behind the first BatchNorm + dropout, chain-tiled (conv_b_bwd -> conv_a_bwd)
     float* part;               // per-workgroup partial gradients, as in TbBwdArgs
+    unsigned *queue_b, *queue_a;   // tile counters of conv_b_bwd / conv_a_bwd, zero when the launch starts
     int64_t n_sites;
     int S;
     int64_t ntiles;

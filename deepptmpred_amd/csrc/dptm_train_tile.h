@@ -369,6 +369,26 @@ __device__ __forceinline__ void x1_from_conv(const ConvSave& cs, int64_t ct, con
     }
 }
 
+// Tiles of a backward launch with more tiles than workgroups are handed out through a counter instead of by workgroup
+// index: the three branches' launches run side by side on the chip, a workgroup may start long after its launch began,
+// and with a fixed share of the tiles per workgroup the late starters would decide when the launch ends.  Every thread
+// of the workgroup calls this (two barriers inside; `slot` is one int of LDS); returns the tile, or a value >= ntiles
+// when none is left.  The counter is zero when the launch starts (the step's first launch clears it).
+// queue == nullptr (a launch with a workgroup per tile): call number `round` of the workgroup returns tile
+// blockIdx.x + round * gridDim.x, without barriers.
+__device__ __forceinline__ int64_t next_tile(unsigned* queue, int* slot, int& round) {
+    if (!queue) return (int64_t)blockIdx.x + (int64_t)(round++) * gridDim.x;
+    __syncthreads();          // the previous tile is finished and its slot value has been read
+    if (threadIdx.x == 0) *slot = (int)atomicAdd(queue, 1u);
+    __syncthreads();
+    return *slot;
+}
+
+// a workgroup that was handed no tile at all still owns a partial buffer that the summing launch reads
+__device__ __forceinline__ void zero_floats(float* __restrict__ dst, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = 0.f;
+}
+
 // ------------------------------------------------------------------------------------ launch helpers
 
 template <typename K>

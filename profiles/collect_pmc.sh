@@ -4,6 +4,8 @@
 #                  2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE, issue counters) of the same command per precision
 #   what = train : the same for `bench.py --train` at 8,192 and 64 sites per step (kernel trace with the branches
 #                  on one stream, DPTM_TRAIN_SERIAL=1, so that a duration is the kernel's own)
+#   what = classes : vector instructions per class (add / mul / fma / transcendental / conversion / integer) of the
+#                  scoring kernels per precision, and the issue cost of each class (tools/issue_cost_probe)
 #   what = probe : do SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU count matrix instructions?  (tools/coexec_probe)
 # Raw output goes to gpurun_out/prof_<tag>/; profiles/summarize_pmc.py turns it into the committed summaries.
 # Every pass is a run of its own under its own time limit; the script stops at the first pass that fails.
@@ -35,6 +37,14 @@ elif [ "$what" = train ]; then
     timeout -s KILL 180 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/train_write_b$batch -- $B > $out/train_write_b$batch.json 2> $out/train_write_b$batch.log
     timeout -s KILL 180 rocprofv3 --pmc $ISSUE --output-format csv -d $out/train_mfma_b$batch -- $B > $out/train_mfma_b$batch.json 2> $out/train_mfma_b$batch.log
     echo train batch $batch done
+  done
+elif [ "$what" = classes ]; then
+  CLS="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32"
+  timeout -k 10 60 $repo/tools/issue_cost_probe > $out/issue_cost.txt 2> $out/issue_cost.log
+  for prec in f32 f16x3 f16 bf16; do
+    B="python3 $repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-variants --no-extras --precision $prec"
+    timeout -s KILL 180 rocprofv3 --pmc $CLS --output-format csv -d $out/cls_$prec -- $B > $out/cls_$prec.json 2> $out/cls_$prec.log
+    echo $prec done
   done
 elif [ "$what" = probe ]; then
   timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --output-format csv -d $out/probe -- $repo/tools/coexec_probe > $out/probe.txt 2> $out/probe.log

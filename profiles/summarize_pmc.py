@@ -5,6 +5,8 @@
   profiles/<tag>_train_b<batch>_serial_kernel_stats.csv, <tag>_train_b<batch>_bench_under_rocprof.json
   profiles/<tag>_train_pmc_traffic.json, <tag>_train_pmc_summary.json  tb_bwd_kernel<51> of the training step
   profiles/<tag>_probe_insts.json                                      what SQ_INSTS_VALU counts (coexec_probe)
+  profiles/<tag>_issue_cost.txt, <tag>_pmc_classes.json                issue cost per instruction class (issue_cost_probe)
+                                                                       and the W=51 scoring kernel's instructions per class
 
 HBM-side traffic per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes): on gfx950 FETCH_SIZE tallies
 the 128-byte requests of 16-byte-per-lane coalesced reads at 64 bytes, WRITE_SIZE is exact.
@@ -144,7 +146,49 @@ if ttraffic:
 if tsummary:
     json.dump(tsummary, open(os.path.join(dst, tag + "_train_pmc_summary.json"), "w"), indent=1)
 
+# ---------------------------------------------------------------- vector instructions per class, priced
+# Cost of one wavefront instruction in units of v_fma_f32 (tools/issue_cost_probe: 32 independent instructions per trip,
+# two wavefronts per SIMD).  add / mul / fma issue at the base rate, transcendentals at ~3.2x, and everything the class
+# counters do not single out (max, compare, select, conversion, integer, packed, cross-lane) is priced at the cost of
+# v_max3_f32 (~1.6x; v_mov, which issues at the base rate, is over-priced by that).
+cost_file = os.path.join(src, "issue_cost.txt")
+classes = {}
+if os.path.exists(cost_file):
+    shutil.copy(cost_file, os.path.join(dst, tag + "_issue_cost.txt"))
+    cost, base_clk = {}, None
+    for ln in open(cost_file):
+        if "clk per wave-instruction" in ln:
+            base_clk = float(ln.split("=")[1].split("clk")[0])
+        elif " x v_fma_f32" in ln:
+            name = ln.split()[0] if not ln.startswith("v_cndmask_b32_e64") else " ".join(ln.split()[:2])
+            cost[name] = float(ln.split("ms")[1].split("x")[0])
+    mf = {"f32": cost.get("v_mfma_32x32x2_f32"), "f16x3": cost.get("v_mfma_32x32x16_bf16"), "f16": cost.get("v_mfma_32x32x16_bf16"),
+          "bf16": cost.get("v_mfma_32x32x16_bf16")}
+    for prec in ("f32", "f16x3", "f16", "bf16"):
+        km, m = pick(per_kernel("cls_" + prec, is_score), "branch_kernel", "51")
+        line = bench_line("cls_%s.json" % prec)
+        if not m or not line or base_clk is None or mf[prec] is None:
+            continue
+        spl = line["roofline"]["sites_per_launch"]
+        g = lambda c: mean(m.get(c, [0.0])) / spl
+        n_mfma = g("SQ_INSTS_MFMA")
+        n_vec = g("SQ_INSTS_VALU") - n_mfma
+        n_add, n_mul, n_fma, n_tr = g("SQ_INSTS_VALU_ADD_F32"), g("SQ_INSTS_VALU_MUL_F32"), g("SQ_INSTS_VALU_FMA_F32"), g("SQ_INSTS_VALU_TRANS_F32")
+        n_other = n_vec - n_add - n_mul - n_fma - n_tr
+        units = (n_add * cost["v_add_f32"] + n_mul * cost["v_mul_f32"] + n_fma * 1.0 + n_tr * cost["v_exp_f32"] +
+                 n_other * cost["v_max3_f32"] + n_mfma * mf[prec])
+        classes[prec] = {"kernel": km, "sites_per_launch": spl, "per_site": {
+            "vector": n_vec, "add_f32": n_add, "mul_f32": n_mul, "fma_f32": n_fma, "trans_f32": n_tr, "cvt": g("SQ_INSTS_VALU_CVT"),
+            "int32": g("SQ_INSTS_VALU_INT32"), "other": n_other, "mfma": n_mfma},
+            "cost_x_fma": {"add_f32": cost["v_add_f32"], "mul_f32": cost["v_mul_f32"], "fma_f32": 1.0, "trans_f32": cost["v_exp_f32"],
+                           "other": cost["v_max3_f32"], "mfma": mf[prec]},
+            "fma_clk_at_2p4ghz": base_clk, "issue_units_per_site": units, "issue_clk_per_site_at_2p4ghz": units * base_clk,
+            "mfma_share_of_issue": n_mfma * mf[prec] / units, "trans_share_of_issue": n_tr * cost["v_exp_f32"] / units,
+            "issue_bound_sites_per_s": 1024 * 2.4e9 / (units * base_clk)}
+    if classes:
+        json.dump(classes, open(os.path.join(dst, tag + "_pmc_classes.json"), "w"), indent=1)
+
 probe = vector_includes_matrix()
 if probe:
     json.dump(probe, open(os.path.join(dst, tag + "_probe_insts.json"), "w"), indent=1)
-print(json.dumps({"traffic": traffic, "summary": summary, "train_traffic": ttraffic, "train_summary": tsummary, "probe": probe}, indent=1))
+print(json.dumps({"traffic": traffic, "summary": summary, "train_traffic": ttraffic, "train_summary": tsummary, "probe": probe, "classes": classes}, indent=1))

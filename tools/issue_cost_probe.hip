@@ -92,6 +92,24 @@ __global__ __launch_bounds__(512) void k_mfma(float* out) {
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
+// 8 independent accumulators of v_mfma_f32_32x32x2_f32
+__global__ __launch_bounds__(512) void k_mfma32(float* out) {
+    f32x16 acc[8];
+    const float a = 0.01f * (threadIdx.x & 7), b = 0.5f;
+    for (int t = 0; t < 8; ++t)
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+    }
+    float s = 0;
+    for (int t = 0; t < 8; ++t)
+        for (int r = 0; r < 16; ++r) s += acc[t][r];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
 template <typename K>
 static float time_ms(K kernel, int blocks, float* out) {
     hipEvent_t a, b;
@@ -159,6 +177,8 @@ int main() {
         const float ms = time_ms(k_mfma, blocks, out);
         // 4 x 8 MFMAs per trip against 32 vector instructions per trip: same instruction count
         printf("%-22s %8.3f ms  %5.2f x v_fma_f32\n", "v_mfma_32x32x16_bf16", ms, ms / base);
+        const float ms32 = time_ms(k_mfma32, blocks, out);
+        printf("%-22s %8.3f ms  %5.2f x v_fma_f32\n", "v_mfma_32x32x2_f32", ms32, ms32 / base);
     }
     hipFree(out);
     return 0;
