@@ -24,7 +24,7 @@ Also reported on the same line (N = 1):
   proteome     many small proteins per call through dptm_score_proteins_device: window
                assembly + ESM row gather on the device (BASELINE north_star 1 and 4).
   sweep        BASELINE config 4 on one GPU: 17 weight sets over 262,144 resident sites.
-  train        BASELINE config 5 on one GPU: training step at batch 64 and 8192, and the Model.fit loop around it.
+  train        BASELINE config 5 on one GPU: training step at batch 64, 8,192 and 32,768, and the Model.fit loop around it.
 Other modes (`--types T`, `--train`, `--proteome`) print their own single line and shard over
 ranks the same way.
 """
@@ -679,6 +679,7 @@ def main() -> None:
         torch.cuda.empty_cache()
         extras["train"] = {"batch64": measure_train(R, 64, 50, 10),
                            "batch8192": measure_train(R, 8192, 5, 2) if n >= 262144 else None,
+                           "batch32768": measure_train(R, 32768, 3, 1) if n >= 262144 else None,
                            "fit_batch64": measure_fit(R, 6400 if n >= 262144 else 640)}
 
     if rank == 0:
