@@ -58,6 +58,7 @@ KERNEL_NAME = {"f32": "branch_kernel<51>", "f16x3": "branch_kernel_h<51,f16x3>",
 TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r2_pmc_traffic.json", "r1_pmc_traffic.json")]
 ISSUE_FILES = [os.path.join(ROOT, "profiles", "r2_pmc_summary.json")]
 TRAIN_TRAFFIC_FILES = [os.path.join(ROOT, "profiles", "r2_train_pmc_traffic.json")]
+ASSEMBLE_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_pmc_assemble.json")
 PEAK_HBM_GBS = 8000.0
 N_SIMD = 1024                        # 256 CUs x 4 SIMDs
 PEAK_CLOCK_GHZ = 2.4
@@ -81,6 +82,19 @@ def measured_traffic(precision: str, sites_per_launch: float):
         if rec and abs(rec.get("sites_per_launch", 0) - sites_per_launch) <= 0.5:
             return rec.get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT)
     return None, None
+
+
+def assemble_traffic(sites_per_launch: int):
+    """HBM-side bytes per all-sites launch of the assembly kernel from the committed --pmc passes of
+    `bench.py --proteome` (profiles/collect_pmc.sh assemble); null for another launch size."""
+    try:
+        with open(ASSEMBLE_TRAFFIC_FILE) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    if rec.get("sites_per_launch") != sites_per_launch:
+        return None, None
+    return rec.get("traffic_bytes_per_launch"), os.path.relpath(ASSEMBLE_TRAFFIC_FILE, ROOT)
 
 
 def issue_bound(precision: str, sites_per_launch: float, avg_launch_s: float):
@@ -542,6 +556,7 @@ def proteome_main(args, R: Ranks) -> None:
     model.scorer.set_precision(args.precision)
     m = measure_proteome(R, model.scorer, args.proteins, args.steps, args.warmup)
     if R.rank == 0:
+        a_traffic, a_file = assemble_traffic(m["assemble_one_launch"]["sites"])
         print(json.dumps({
             "metric": "windows scored/sec (proteome: many proteins per call, device-side assembly)",
             "value": m["sites_per_s"], "unit": "sites/s", "n_gpus": R.world, "steps": args.steps,
@@ -553,7 +568,10 @@ def proteome_main(args, R: Ranks) -> None:
                        "parallelism": f"dp{R.world} (proteins sharded, no collective)"},
             "roofline": {"bound": "hbm", "kernel": "assemble_kernel (all sites in one launch)",
                          "achieved": m["assemble_one_launch"]["gbs_algorithmic"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": m["assemble_one_launch"]["frac_of_hbm_peak"], "traffic": None},
+                         "frac": m["assemble_one_launch"]["frac_of_hbm_peak"], "traffic": a_traffic,
+                         "traffic_source": f"{a_file} (offline rocprofv3 --pmc passes of this command)" if a_file else None,
+                         "avg_launch_ms": m["assemble_one_launch"]["avg_launch_ms"],
+                         "bytes_per_site": ASSEMBLE_BYTES_PER_SITE},
             "proteome": m}))
     R.finish()
 

@@ -4,6 +4,7 @@
 #                  2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE, issue counters) of the same command per precision
 #   what = train : the same for `bench.py --train` at 8,192 and 64 sites per step (kernel trace with the branches
 #                  on one stream, DPTM_TRAIN_SERIAL=1, so that a duration is the kernel's own)
+#   what = assemble : FETCH_SIZE / WRITE_SIZE of the window-assembly kernel in `bench.py --proteome`
 #   what = classes : vector instructions per class (add / mul / fma / transcendental / conversion / integer) of the
 #                  scoring kernels per precision, and the issue cost of each class (tools/issue_cost_probe)
 #   what = probe : do SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU count matrix instructions?  (tools/coexec_probe)
@@ -38,6 +39,11 @@ elif [ "$what" = train ]; then
     timeout -s KILL 180 rocprofv3 --pmc $ISSUE --output-format csv -d $out/train_mfma_b$batch -- $B > $out/train_mfma_b$batch.json 2> $out/train_mfma_b$batch.log
     echo train batch $batch done
   done
+elif [ "$what" = assemble ]; then
+  B="python3 $repo/bench.py --proteome --steps 1 --warmup 0 --no-cpu-baseline"
+  timeout -s KILL 180 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/asm_fetch -- $B > $out/asm_fetch.json 2> $out/asm_fetch.log
+  timeout -s KILL 180 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/asm_write -- $B > $out/asm_write.json 2> $out/asm_write.log
+  echo assemble done
 elif [ "$what" = classes ]; then
   CLS="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32"
   timeout -k 10 60 $repo/tools/issue_cost_probe > $out/issue_cost.txt 2> $out/issue_cost.log

@@ -5,6 +5,7 @@
   profiles/<tag>_train_b<batch>_serial_kernel_stats.csv, <tag>_train_b<batch>_bench_under_rocprof.json
   profiles/<tag>_train_pmc_traffic.json, <tag>_train_pmc_summary.json  tb_bwd_kernel<51> of the training step
   profiles/<tag>_probe_insts.json                                      what SQ_INSTS_VALU counts (coexec_probe)
+  profiles/<tag>_pmc_assemble.json                                     HBM-side traffic of the window-assembly kernel
   profiles/<tag>_issue_cost.txt, <tag>_pmc_classes.json                issue cost per instruction class (issue_cost_probe)
                                                                        and the W=51 scoring kernel's instructions per class
 
@@ -188,7 +189,25 @@ if os.path.exists(cost_file):
     if classes:
         json.dump(classes, open(os.path.join(dst, tag + "_pmc_classes.json"), "w"), indent=1)
 
+# ---------------------------------------------------------------- window assembly (bench.py --proteome)
+# the launches over ALL sites (bench.py times five of them) are the ones with the largest grid
+asm = {}
+fa = per_kernel("asm_fetch", lambda n: "assemble_kernel" in n)
+wa = per_kernel("asm_write", lambda n: "assemble_kernel" in n)
+line = bench_line("asm_fetch.json")
+if fa and wa and line:
+    f = list(fa.values())[0]
+    w = list(wa.values())[0]
+    big_f = [v for v in f["FETCH_SIZE"] if v >= 0.5 * max(f["FETCH_SIZE"])]
+    big_w = [v for v in w["WRITE_SIZE"] if v >= 0.5 * max(w["WRITE_SIZE"])]
+    sites = line["proteome"]["assemble_one_launch"]["sites"]
+    asm = {"kernel": "assemble_kernel", "sites_per_launch": sites, "launches": len(big_f),
+           "FETCH_SIZE_KiB_per_launch": mean(big_f), "WRITE_SIZE_KiB_per_launch": mean(big_w),
+           "traffic_bytes_per_launch": (2 * mean(big_f) + mean(big_w)) * 1024,
+           "algorithmic_bytes_per_launch": sites * 117}
+    json.dump(asm, open(os.path.join(dst, tag + "_pmc_assemble.json"), "w"), indent=1)
+
 probe = vector_includes_matrix()
 if probe:
     json.dump(probe, open(os.path.join(dst, tag + "_probe_insts.json"), "w"), indent=1)
-print(json.dumps({"traffic": traffic, "summary": summary, "train_traffic": ttraffic, "train_summary": tsummary, "probe": probe, "classes": classes}, indent=1))
+print(json.dumps({"traffic": traffic, "summary": summary, "train_traffic": ttraffic, "train_summary": tsummary, "probe": probe, "classes": classes, "assemble": asm}, indent=1))
