@@ -583,6 +583,8 @@ __device__ __forceinline__ void assemble_flush(const uint8_t* img, uint8_t* __re
     for (int o = 16 * whole + threadIdx.x; o < bytes; o += blockDim.x) out[o] = img[o];
 }
 
+// WORDS: the residue array starts on a 4-byte boundary and is read in 32-bit words
+template <bool WORDS>
 __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t img[kAsmImgBytes + 256];   // + a spare byte per thread
     const int tid = threadIdx.x;
@@ -611,10 +613,32 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
             // instead of round a branch
             const int last = (int)len - 1;
             uint8_t code[13];
+            if (WORDS) {
+                // the 13 bytes arrive as the five aligned 32-bit words that hold them (a fetch per byte is what
+                // bounds this kernel otherwise); a word outside the protein's own words is replaced by the nearest
+                // one of them -- every byte it stands for is padding -- so nothing beyond the residue array's first
+                // and last word is touched
+                const int64_t g = base + i0 + 13 * q;           // first byte, as an offset into codes (may be negative)
+                const uint32_t sh = (uint32_t)(g & 3);
+                const int64_t d0 = g >> 2, dlo = base >> 2, dhi = (base + last) >> 2;
+                const uint32_t* cw = reinterpret_cast<const uint32_t*>(a.codes);
+                uint32_t dw[5];
 #pragma unroll
-            for (int k = 0; k < 13; ++k) {
-                const int i = i0 + 13 * q + k;
-                code[k] = src[i < 0 ? 0 : (i > last ? last : i)];
+                for (int j = 0; j < 5; ++j) {
+                    const int64_t d = d0 + j;
+                    dw[j] = cw[d < dlo ? dlo : (d > dhi ? dhi : d)];
+                }
+#pragma unroll
+                for (int k = 0; k < 13; ++k) {
+                    const uint32_t w4 = __builtin_amdgcn_alignbyte(dw[(k >> 2) + 1], dw[k >> 2], sh);
+                    code[k] = (uint8_t)(w4 >> (8 * (k & 3)));
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 13; ++k) {
+                    const int i = i0 + 13 * q + k;
+                    code[k] = src[i < 0 ? 0 : (i > last ? last : i)];
+                }
             }
             const int spare = kAsmImgBytes + tid;
 #pragma unroll
@@ -713,7 +737,10 @@ hipError_t launch_assemble(const AssembleArgs& a, hipStream_t st) {
     // multiple of 64*W); single bytes otherwise
     k.words = ((reinterpret_cast<uintptr_t>(a.t21) | reinterpret_cast<uintptr_t>(a.t33) |
                 reinterpret_cast<uintptr_t>(a.t51)) & 15) == 0;
-    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)blocks), dim3(256), 0, st, k);
+    if ((reinterpret_cast<uintptr_t>(a.codes) & 3) == 0)
+        hipLaunchKernelGGL(assemble_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, k);
+    else
+        hipLaunchKernelGGL(assemble_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, k);
     return hipGetLastError();
 }
 

@@ -140,11 +140,12 @@ def test_large_batch_matches_device_form_and_assembled_inputs(model, weights):
     assert np.abs(host[k] - ref).max() < TOL
 
 
-@pytest.mark.parametrize("byte_offset", [0, 1, 4])
-def test_assemble_proteins_bit_exact(model, byte_offset):
+@pytest.mark.parametrize("byte_offset,codes_offset", [(0, 0), (1, 0), (4, 0), (0, 1), (0, 2)])
+def test_assemble_proteins_bit_exact(model, byte_offset, codes_offset):
     """Every residue of 40 proteins (lengths 1..300) as a site: windows equal the reference's string code
     (predict.py:529-560) byte for byte and the row index follows predict.py:493; also with output arrays
-    that start off a 16-byte boundary (byte stores instead of 16-byte stores)."""
+    that start off a 16-byte boundary (byte stores instead of 16-byte stores), and with a residue array that
+    starts off a 4-byte boundary (a fetch per byte instead of per 32-bit word)."""
     import torch
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(9)
@@ -161,9 +162,13 @@ def test_assemble_proteins_bit_exact(model, byte_offset):
             for w in (21, 33, 51)]
     want_row = np.where(pos - 1 < rows[prot], esm_off[prot] + pos - 1, -1)
     d = [torch.from_numpy(a).to(dev) for a in (codes, seq_off, esm_off, pos, prot)]
+    shifted = torch.full((len(codes) + 8,), 77, dtype=torch.uint8, device=dev)     # 77: not a residue code
+    shifted[codes_offset:codes_offset + len(codes)] = d[0]
+    codes_ptr = shifted.data_ptr() + codes_offset
+    assert shifted.data_ptr() % 4 == 0
     raw = [torch.full((n * w + 8,), 255, dtype=torch.uint8, device=dev) for w in (21, 33, 51)]
     erow = torch.empty(n, dtype=torch.int32, device=dev)
-    model.scorer.assemble_proteins_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+    model.scorer.assemble_proteins_device(codes_ptr, d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
                                           n, *[t.data_ptr() + byte_offset for t in raw], erow.data_ptr(),
                                           torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
