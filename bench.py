@@ -688,17 +688,25 @@ def main() -> None:
     # configs 4 and 5 and the host / proteome forms, on one GPU, beside the headline (never `value`)
     extras = {}
     if world == 1 and not args.no_extras:
-        extras["streamed_from_host"] = measure_streamed(model, min(n, 262144))
-        extras["proteome"] = measure_proteome(R, sc, 20000 if n >= 262144 else 200, 3, 1)
+        def guarded(fn, *a):
+            """a side measurement that fails leaves its error in the line instead of taking the headline with it"""
+            try:
+                return fn(*a)
+            except Exception as e:      # noqa: BLE001 -- reported, not hidden
+                torch.cuda.synchronize()
+                return {"error": f"{type(e).__name__}: {e}"}
+
+        extras["streamed_from_host"] = guarded(measure_streamed, model, min(n, 262144))
+        extras["proteome"] = guarded(measure_proteome, R, sc, 20000 if n >= 262144 else 200, 3, 1)
         ns = min(n, 262144)
         xs = [t[:ns] for t in x]
-        extras["sweep"] = measure_sweep(R, 17 if n >= 262144 else 3, ns, 2, 1, args.precision, xs)
+        extras["sweep"] = guarded(measure_sweep, R, 17 if n >= 262144 else 3, ns, 2, 1, args.precision, xs)
         del x, xs, out
         torch.cuda.empty_cache()
-        extras["train"] = {"batch64": measure_train(R, 64, 50, 10),
-                           "batch8192": measure_train(R, 8192, 5, 2) if n >= 262144 else None,
-                           "batch32768": measure_train(R, 32768, 3, 1) if n >= 262144 else None,
-                           "fit_batch64": measure_fit(R, 6400 if n >= 262144 else 640)}
+        extras["train"] = {"batch64": guarded(measure_train, R, 64, 50, 10),
+                           "batch8192": guarded(measure_train, R, 8192, 5, 2) if n >= 262144 else None,
+                           "batch32768": guarded(measure_train, R, 32768, 3, 1) if n >= 262144 else None,
+                           "fit_batch64": guarded(measure_fit, R, 6400 if n >= 262144 else 640)}
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
