@@ -563,14 +563,19 @@ __global__ __launch_bounds__(512) void dense_small_kernel(DenseArgs p) {
 // Window assembly (predict.py:529-560) and the ESM row index (predict.py:487-501) for sites of many
 // proteins at once: column c of the W-window of 1-based, protein-local position `pos` is residue
 // pos-1-(W-1)/2+c of that protein, or the padding code 20 outside 0..L-1 (also for codes > 20).
-// A workgroup owns kAsmSites consecutive sites, whose three output ranges [s0*W, (s0+kAsmSites)*W) are
-// contiguous bytes.  The W=33 and W=21 windows of a site are the middle of its W=51 window, so every residue
-// byte is fetched and clamped ONCE (four threads per site, through the vector cache: neighbouring sites of a
-// protein share most of their windows) and dropped into up to three LDS images that hold the tile's output
-// bytes in output order; the images then leave as 16-byte stores, 1 KiB per wavefront instruction.
+// A workgroup owns kAsmSites = 256 consecutive sites, whose three output ranges [s0*W, (s0+256)*W) are contiguous
+// bytes; they are composed in LDS images and leave as 16-byte stores, 1 KiB per wavefront instruction.
+// One thread per site: the W=33 and W=21 windows are the middle of the W=51 window, so the thread fetches the 51
+// residue bytes once, as the (at most) 14 aligned 32-bit words that hold them, shifts them into 13 packed words,
+// replaces codes above 20 and the bytes outside the protein by the padding code four bytes at a time, and writes
+// three runs (51, 33 and 21 bytes) into the images.  Wavefront w takes the sites s = 4*lane + w: 51, 33 and 21 are
+// odd, so the byte alignment of a run's start, (W*s) mod 4, is then the same for all lanes of a wavefront, and a
+// run is a few single bytes at its ends and aligned 32-bit words in between (14 LDS stores for 51 bytes instead of
+// 51; lanes 4 sites apart are an odd number of words apart: no bank conflicts).  The LDS stores and the per-byte
+// work were what bounded the earlier forms of this kernel.
 // seq_off == nullptr: one protein of length a.L (site_protein is then not read).
 // ------------------------------------------------------------------------------------
-constexpr int kAsmSites = 64;
+constexpr int kAsmSites = 256;
 constexpr int kAsmImg21 = 0, kAsmImg33 = kAsmSites * 21, kAsmImg51 = kAsmImg33 + kAsmSites * 33;   // byte offsets
 constexpr int kAsmImgBytes = kAsmSites * (21 + 33 + 51);
 static_assert(kAsmImg33 % 16 == 0 && kAsmImg51 % 16 == 0 && kAsmImgBytes % 16 == 0, "images start on 16-byte boundaries");
@@ -583,12 +588,58 @@ __device__ __forceinline__ void assemble_flush(const uint8_t* img, uint8_t* __re
     for (int o = 16 * whole + threadIdx.x; o < bytes; o += blockDim.x) out[o] = img[o];
 }
 
+// four packed window bytes starting at byte b (compile-time) of r[0..12]
+template <int B>
+__device__ __forceinline__ uint32_t assemble_word(const uint32_t (&r)[14]) {
+    constexpr int w = B >> 2, sft = B & 3;
+    return sft == 0 ? r[w] : __builtin_amdgcn_alignbyte(r[w + 1], r[w], (uint32_t)sft);
+}
+
+// wp[k] = window bytes [B + 4k, B + 4k + 4) for k = K .. WORDS-1
+template <int B, int K, int WORDS>
+__device__ __forceinline__ void assemble_words(uint32_t* wp, const uint32_t (&r)[14]) {
+    if constexpr (K < WORDS) {
+        wp[K] = assemble_word<B + 4 * K>(r);
+        assemble_words<B, K + 1, WORDS>(wp, r);
+    }
+}
+
+// Window bytes [FROM, FROM + N) of r to LDS at dst, whose address is AL (mod 4): single bytes / a 16-bit piece up
+// to the first word boundary, aligned words, then what is left.
+template <int AL, int FROM, int N>
+__device__ __forceinline__ void assemble_run(uint8_t* dst, const uint32_t (&r)[14]) {
+    constexpr int head = (4 - AL) & 3;
+    if (head != 0) {
+        const uint32_t v = assemble_word<FROM>(r);
+        if (head & 1) dst[0] = (uint8_t)v;                                                        // AL = 1 or 3
+        if (head & 2) *reinterpret_cast<uint16_t*>(dst + (head & 1)) = (uint16_t)(v >> (8 * (head & 1)));   // AL = 1 or 2
+    }
+    constexpr int words = (N - head) >> 2;
+    uint32_t* wp = reinterpret_cast<uint32_t*>(dst + head);
+    assemble_words<FROM + head, 0, words>(wp, r);
+    constexpr int done = head + 4 * words, tail = N - done;
+    if (tail != 0) {
+        const uint32_t v = assemble_word<FROM + done>(r);
+        if (tail & 2) *reinterpret_cast<uint16_t*>(dst + done) = (uint16_t)v;
+        if (tail & 1) dst[done + (tail & 2)] = (uint8_t)(v >> (8 * (tail & 2)));
+    }
+}
+
+// the three runs of one site; S = site index (mod 4) of the wavefront: 51 = 3, 33 = 21 = 1 (mod 4)
+template <int S>
+__device__ __forceinline__ void assemble_runs(uint8_t* img, int sl, const uint32_t (&r)[14]) {
+    assemble_run<(3 * S) & 3, 0, 51>(img + kAsmImg51 + sl * 51, r);
+    assemble_run<S, 9, 33>(img + kAsmImg33 + sl * 33, r);        // columns 9..41
+    assemble_run<S, 15, 21>(img + kAsmImg21 + sl * 21, r);       // columns 15..35
+}
+
 // WORDS: the residue array starts on a 4-byte boundary and is read in 32-bit words
 template <bool WORDS>
 __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
-    __shared__ __attribute__((aligned(16))) uint8_t img[kAsmImgBytes + 256];   // + a spare byte per thread
+    __shared__ __attribute__((aligned(16))) uint8_t img[kAsmImgBytes];
     const int tid = threadIdx.x;
-    const int sl = tid >> 2, q = tid & 3;          // four threads per site; thread q takes columns 13q .. 13q+12 of W=51
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sl = 4 * (tid & 63) + w;
     const int64_t tiles = (a.n + kAsmSites - 1) / kAsmSites;
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int64_t s0 = tile * kAsmSites;
@@ -604,50 +655,61 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
                 erow0 = a.esm_off[p];
                 erows = a.esm_off[p + 1] - erow0;
             }
-            if (q == 0) a.esm_row[site] = (pos - 1 < erows) ? (int32_t)(erow0 + pos - 1) : -1;
-            const int i0 = pos - 1 - 25;
-            const uint8_t* src = a.codes + base;
-            // every residue byte of the thread is requested before the first is used: the loads are unconditional
-            // (index clamped into the protein, which holds at least the site's own residue), the padding code is
-            // chosen afterwards, and a byte that a window does not hold goes to a spare byte of the thread's own
-            // instead of round a branch
+            a.esm_row[site] = (pos - 1 < erows) ? (int32_t)(erow0 + pos - 1) : -1;
+            const int i0 = pos - 1 - 25;                      // residue of window column 0
             const int last = (int)len - 1;
-            uint8_t code[13];
+            // r[j] = window bytes 4j .. 4j+3 (r[12]: bytes 48..50 and one more), r[13] = 0
+            uint32_t r[14];
             if (WORDS) {
-                // the 13 bytes arrive as the five aligned 32-bit words that hold them (a fetch per byte is what
-                // bounds this kernel otherwise); a word outside the protein's own words is replaced by the nearest
-                // one of them -- every byte it stands for is padding -- so nothing beyond the residue array's first
-                // and last word is touched
-                const int64_t g = base + i0 + 13 * q;           // first byte, as an offset into codes (may be negative)
+                // every word is requested before the first is used; a word outside the protein's own words is replaced
+                // by the nearest one of them -- every byte it stands for is padding -- so nothing beyond the residue
+                // array's first and last word is touched
+                const int64_t g = base + i0;                 // first byte, as an offset into codes (may be negative)
                 const uint32_t sh = (uint32_t)(g & 3);
                 const int64_t d0 = g >> 2, dlo = base >> 2, dhi = (base + last) >> 2;
                 const uint32_t* cw = reinterpret_cast<const uint32_t*>(a.codes);
-                uint32_t dw[5];
+                uint32_t dw[14];
 #pragma unroll
-                for (int j = 0; j < 5; ++j) {
+                for (int j = 0; j < 14; ++j) {
                     const int64_t d = d0 + j;
                     dw[j] = cw[d < dlo ? dlo : (d > dhi ? dhi : d)];
                 }
 #pragma unroll
-                for (int k = 0; k < 13; ++k) {
-                    const uint32_t w4 = __builtin_amdgcn_alignbyte(dw[(k >> 2) + 1], dw[k >> 2], sh);
-                    code[k] = (uint8_t)(w4 >> (8 * (k & 3)));
-                }
+                for (int j = 0; j < 13; ++j) r[j] = __builtin_amdgcn_alignbyte(dw[j + 1], dw[j], sh);
             } else {
+                const uint8_t* src = a.codes + base;
 #pragma unroll
-                for (int k = 0; k < 13; ++k) {
-                    const int i = i0 + 13 * q + k;
-                    code[k] = src[i < 0 ? 0 : (i > last ? last : i)];
+                for (int j = 0; j < 13; ++j) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = i0 + 4 * j + e;
+                        v |= (uint32_t)src[i < 0 ? 0 : (i > last ? last : i)] << (8 * e);
+                    }
+                    r[j] = v;
                 }
             }
-            const int spare = kAsmImgBytes + tid;
+            r[13] = 0u;
+            // bytes [lo, hi) of the window lie inside the protein
+            const int lo = min(max(-i0, 0), 52), hi = min(max(last + 1 - i0, 0), 52);
 #pragma unroll
-            for (int k = 0; k < 13; ++k) {
-                const int c = 13 * q + k, i = i0 + c;
-                const uint8_t v = (i < 0 || i > last || code[k] > 20) ? (uint8_t)20 : code[k];
-                img[c < 51 ? kAsmImg51 + sl * 51 + c : spare] = v;
-                img[(c >= 9 && c < 42) ? kAsmImg33 + sl * 33 + c - 9 : spare] = v;
-                img[(c >= 15 && c < 36) ? kAsmImg21 + sl * 21 + c - 15 : spare] = v;
+            for (int j = 0; j < 13; ++j) {
+                uint32_t x = r[j];
+                // codes above 20 -> 20, four bytes at a time: bit 7 of (x & 0x7f) + 107 is set where the low seven bits
+                // are 21 or more, bit 7 of x itself where the byte is 128 or more
+                const uint32_t m7 = (((x & 0x7f7f7f7fu) + 0x6b6b6b6bu) | x) & 0x80808080u;
+                const uint32_t big = m7 | (m7 - (m7 >> 7));                    // 0xff in every such byte
+                x = (x & ~big) | (0x14141414u & big);
+                // bytes of this word inside the protein: [a4, b4) of 0..4
+                const int a4 = min(max(lo - 4 * j, 0), 4), b4 = min(max(hi - 4 * j, 0), 4);
+                const uint32_t in = (uint32_t)((1ull << (8 * b4)) - 1ull) & ~(uint32_t)((1ull << (8 * a4)) - 1ull);
+                r[j] = (x & in) | (0x14141414u & ~in);
+            }
+            switch (w) {          // the same for the whole wavefront
+                case 0: assemble_runs<0>(img, sl, r); break;
+                case 1: assemble_runs<1>(img, sl, r); break;
+                case 2: assemble_runs<2>(img, sl, r); break;
+                default: assemble_runs<3>(img, sl, r); break;
             }
         }
         __syncthreads();
