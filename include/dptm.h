@@ -160,7 +160,9 @@ int dptm_score_proteins_device(dptm_handle* h, const uint8_t* codes, const int64
 
 /* Window assembly alone for sites of many proteins (predict.py:529-560, 487-501 on the device).
  * DEVICE pointers, validated input.  Writes tok21/tok33/tok51 uint8 [n][W] and esm_row int32 [n]
- * (row of the concatenated tables, or -1 for a zero row).  One launch covers all n sites. */
+ * (row of the concatenated tables, or -1 for a zero row).  One launch covers all n sites.  The arrays may
+ * start at any byte; the kernel is at its fastest when codes starts on a 4-byte boundary (residues are then
+ * fetched as 32-bit words) and the three outputs on 16-byte boundaries (16-byte stores). */
 int dptm_assemble_proteins_device(dptm_handle* h, const uint8_t* codes, const int64_t* seq_offsets,
                                   const int64_t* esm_offsets, const int32_t* positions,
                                   const int32_t* site_protein, int64_t n, uint8_t* tok21, uint8_t* tok33,
