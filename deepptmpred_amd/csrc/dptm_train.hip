@@ -805,7 +805,7 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
     // longest) on the step's main stream `st`, the structure / ESM layers of a small batch on a third side stream `ss`.
     // (A process has four hardware queues: a fifth concurrent stream would share one and serialise behind it.)
     hipStream_t bstream[3] = {t->serial ? st : t->aux[0], t->serial ? st : t->aux[1], st};
-    hipStream_t ss = small && !t->serial ? t->aux[2] : st;
+    hipStream_t ss = !t->serial ? t->aux[2] : st;      // per-site layers that run next to the branches
     hipStream_t side[3] = {bstream[0], bstream[1], ss};
     // the longest branch first: its launches are then the first the host hands to the device
     auto branches = [&](bool forward, int first, int last) -> int {
@@ -899,29 +899,30 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
                   kEsm, none, 512));
         if ((rc = branches(false, 0, 1))) return rc;
     } else {
-        if ((rc = branches(true, 0, 1))) return rc;
+        if ((rc = branches(true, 0, 2))) return rc;
+        // structure and ESM layers on the fourth stream, next to the three branches
+        Ctx cf{t, ss, t->W, t->G, &t->sc[3]};
         // struct branch (model.py:187-189)
-        auto dense_swish = [&](GemmArgs g, float* act, int64_t lda) {     // pre-activation to g.out, swish of it to act
+        auto dense_swish = [&](GemmArgs g, float* act, int64_t lda, hipStream_t s) {     // pre-activation to g.out, swish of it to act
             g.act_out = act; g.lda = lda;
-            return t_gemm(g, false, st);
+            return t_gemm(g, false, s);
         };
-        T_TRY(dense_swish(ga(strct, 8, c.w(pm.strct.k), 128, c.w(pm.strct.b), t->sa, 128, 0, B, 8, 128), t->sy, 128));
-        if ((rc = bn_train_fwd(c, t->sy, t->concat, kConcat, 192, B, 128, pm.strct.bn, t->smi))) return rc;
-        T_TRY(t_dropout(t->concat + 192, B, 128, kConcat, 0, seed, 24 + 0, rt.dense, st));
+        T_TRY(dense_swish(ga(strct, 8, c.w(pm.strct.k), 128, c.w(pm.strct.b), t->sa, 128, 0, B, 8, 128), t->sy, 128, ss));
+        if ((rc = bn_train_fwd(cf, t->sy, t->concat, kConcat, 192, B, 128, pm.strct.bn, t->smi))) return rc;
+        T_TRY(t_dropout(t->concat + 192, B, 128, kConcat, 0, seed, 24 + 0, rt.dense, ss));
         // ESM branch (model.py:191-194)
-        T_TRY(dense_swish(ga(esm, kEsm, c.w(pm.esm1.k), 512, c.w(pm.esm1.b), t->ea, 512, 0, B, kEsm, 512), t->ey, 512));
-        if ((rc = bn_train_fwd(c, t->ey, t->e1, 512, 0, B, 512, pm.esm1.bn, t->emi))) return rc;
-        T_TRY(t_dropout(t->e1, B, 512, 512, 0, seed, 24 + 1, rt.dense, st));
+        T_TRY(dense_swish(ga(esm, kEsm, c.w(pm.esm1.k), 512, c.w(pm.esm1.b), t->ea, 512, 0, B, kEsm, 512), t->ey, 512, ss));
+        if ((rc = bn_train_fwd(cf, t->ey, t->e1, 512, 0, B, 512, pm.esm1.bn, t->emi))) return rc;
+        T_TRY(t_dropout(t->e1, B, 512, 512, 0, seed, 24 + 1, rt.dense, ss));
         // swish straight into the concat columns 320..575
-        T_TRY(dense_swish(ga(t->e1, 512, c.w(pm.esm2.k), 256, c.w(pm.esm2.b), t->e2a, 256, 0, B, 512, 256), t->concat + 320, kConcat));
-        if ((rc = branches(true, 2, 2))) return rc;
+        T_TRY(dense_swish(ga(t->e1, 512, c.w(pm.esm2.k), 256, c.w(pm.esm2.b), t->e2a, 256, 0, B, 512, 256), t->concat + 320, kConcat, ss));
         if ((rc = join(0))) return rc;              // pooled branch outputs are in concat
         T_TRY(t_dropout(t->concat, B, kConcat, kConcat, 0, seed, 24 + 2, rt.dense, st));
         // trunk (model.py:200-205)
-        T_TRY(dense_swish(ga(t->concat, kConcat, c.w(pm.t1.k), 512, c.w(pm.t1.b), t->t1a, 512, 0, B, kConcat, 512), t->t1y, 512));
+        T_TRY(dense_swish(ga(t->concat, kConcat, c.w(pm.t1.k), 512, c.w(pm.t1.b), t->t1a, 512, 0, B, kConcat, 512), t->t1y, 512, st));
         if ((rc = bn_train_fwd(c, t->t1y, t->t1z, 512, 0, B, 512, pm.t1.bn, t->t1mi))) return rc;
         T_TRY(t_dropout(t->t1z, B, 512, 512, 0, seed, 24 + 3, rt.dense, st));
-        T_TRY(dense_swish(ga(t->t1z, 512, c.w(pm.t2.k), 256, c.w(pm.t2.b), t->t2a, 256, 0, B, 512, 256), t->t2y, 256));
+        T_TRY(dense_swish(ga(t->t1z, 512, c.w(pm.t2.k), 256, c.w(pm.t2.b), t->t2a, 256, 0, B, 512, 256), t->t2y, 256, st));
         if ((rc = bn_train_fwd(c, t->t2y, t->t2z, 256, 0, B, 256, pm.t2.bn, t->t2mi))) return rc;
         // ---------------- head, loss and its gradient (trainer.py:36-54)
         T_TRY(t_head_loss(t->t2z, c.w(pm.head.k), c.w(pm.head.b), labels, B, t->d_step, t->proba, t->d_loss, t->d256a,
@@ -930,33 +931,37 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
         // trunk 2: BN -> swish -> dense
         if ((rc = bn_train_bwd(c, t->d256a, 256, 0, t->t2y, t->d256b, B, 256, t->t2mi, pm.t2.bn))) return rc;
         T_TRY(t_swish_bwd(t->t2a, t->d256b, t->d256b, B * 256, st));
-        T_TRY(t_gemm_tn(gt(t->t1z, 512, 0, t->d256b, 256, 0, c.g(pm.t2.k), 256, c.g(pm.t2.b), B, 512, 256), st));
         T_TRY(t_gemm(ga(t->d256b, 256, c.w(pm.t2.k), 256, nullptr, t->d512a, 512, 0, B, 256, 512), true, st));
         T_TRY(t_dropout(t->d512a, B, 512, 512, 0, seed, 24 + 3, rt.dense, st));
         if ((rc = bn_train_bwd(c, t->d512a, 512, 0, t->t1y, t->d512b, B, 512, t->t1mi, pm.t1.bn))) return rc;
         T_TRY(t_swish_bwd(t->t1a, t->d512b, t->d512b, B * 512, st));
-        T_TRY(t_gemm_tn(gt(t->concat, kConcat, 0, t->d512b, 512, 0, c.g(pm.t1.k), 512, c.g(pm.t1.b), B, kConcat, 512), st));
         T_TRY(t_gemm(ga(t->d512b, 512, c.w(pm.t1.k), 512, nullptr, t->dconcat, kConcat, 0, B, 512, kConcat), true, st));
         T_TRY(t_dropout(t->dconcat, B, kConcat, kConcat, 0, seed, 24 + 2, rt.dense, st));
         // d(concat) is complete: the sequence branches go backward side by side with the ESM and structure layers below
         // (each owns its parameters' gradients)
         if ((rc = fork(1))) return rc;
         if ((rc = branches(false, 0, 2))) return rc;
+        // The trunk's two weight gradients wait until here -- nothing on the way to d(concat) needs them -- and run with
+        // the ESM / structure layers on the fourth stream, next to the branches instead of holding the whole chip up.
+        // (One stream for all of them: the layers below reuse d512b.)
+        Ctx cs{t, ss, t->W, t->G, &t->sc[3]};
+        T_TRY(t_gemm_tn(gt(t->t1z, 512, 0, t->d256b, 256, 0, c.g(pm.t2.k), 256, c.g(pm.t2.b), B, 512, 256), ss));
+        T_TRY(t_gemm_tn(gt(t->concat, kConcat, 0, t->d512b, 512, 0, c.g(pm.t1.k), 512, c.g(pm.t1.b), B, kConcat, 512), ss));
         // ESM branch: d(concat[:,320:]) -> swish -> dense2 -> dropout -> BN -> swish -> dense1
-        T_TRY(t_copy_cols(t->d256a, 256, 0, t->dconcat, kConcat, 320, B, 256, false, st));
-        T_TRY(t_swish_bwd(t->e2a, t->d256a, t->d256a, B * 256, st));
-        T_TRY(t_gemm_tn(gt(t->e1, 512, 0, t->d256a, 256, 0, c.g(pm.esm2.k), 256, c.g(pm.esm2.b), B, 512, 256), st));
-        T_TRY(t_gemm(ga(t->d256a, 256, c.w(pm.esm2.k), 256, nullptr, t->d512a, 512, 0, B, 256, 512), true, st));
-        T_TRY(t_dropout(t->d512a, B, 512, 512, 0, seed, 24 + 1, rt.dense, st));
-        if ((rc = bn_train_bwd(c, t->d512a, 512, 0, t->ey, t->d512b, B, 512, t->emi, pm.esm1.bn))) return rc;
-        T_TRY(t_swish_bwd(t->ea, t->d512b, t->d512b, B * 512, st));
-        T_TRY(t_gemm_tn(gt(esm, kEsm, 0, t->d512b, 512, 0, c.g(pm.esm1.k), 512, c.g(pm.esm1.b), B, kEsm, 512), st));
+        T_TRY(t_copy_cols(t->d256a, 256, 0, t->dconcat, kConcat, 320, B, 256, false, ss));
+        T_TRY(t_swish_bwd(t->e2a, t->d256a, t->d256a, B * 256, ss));
+        T_TRY(t_gemm_tn(gt(t->e1, 512, 0, t->d256a, 256, 0, c.g(pm.esm2.k), 256, c.g(pm.esm2.b), B, 512, 256), ss));
+        T_TRY(t_gemm(ga(t->d256a, 256, c.w(pm.esm2.k), 256, nullptr, t->d512a, 512, 0, B, 256, 512), true, ss));
+        T_TRY(t_dropout(t->d512a, B, 512, 512, 0, seed, 24 + 1, rt.dense, ss));
+        if ((rc = bn_train_bwd(cs, t->d512a, 512, 0, t->ey, t->d512b, B, 512, t->emi, pm.esm1.bn))) return rc;
+        T_TRY(t_swish_bwd(t->ea, t->d512b, t->d512b, B * 512, ss));
+        T_TRY(t_gemm_tn(gt(esm, kEsm, 0, t->d512b, 512, 0, c.g(pm.esm1.k), 512, c.g(pm.esm1.b), B, kEsm, 512), ss));
         // struct branch: d(concat[:,192:320]) -> dropout -> BN -> swish -> dense
-        T_TRY(t_copy_cols(t->d128, 128, 0, t->dconcat, kConcat, 192, B, 128, false, st));
-        T_TRY(t_dropout(t->d128, B, 128, 128, 0, seed, 24 + 0, rt.dense, st));
-        if ((rc = bn_train_bwd(c, t->d128, 128, 0, t->sy, t->d512a, B, 128, t->smi, pm.strct.bn))) return rc;
-        T_TRY(t_swish_bwd(t->sa, t->d512a, t->d512a, B * 128, st));
-        T_TRY(t_gemm_tn(gt(strct, 8, 0, t->d512a, 128, 0, c.g(pm.strct.k), 128, c.g(pm.strct.b), B, 8, 128), st));
+        T_TRY(t_copy_cols(t->d128, 128, 0, t->dconcat, kConcat, 192, B, 128, false, ss));
+        T_TRY(t_dropout(t->d128, B, 128, 128, 0, seed, 24 + 0, rt.dense, ss));
+        if ((rc = bn_train_bwd(cs, t->d128, 128, 0, t->sy, t->d512a, B, 128, t->smi, pm.strct.bn))) return rc;
+        T_TRY(t_swish_bwd(t->sa, t->d512a, t->d512a, B * 128, ss));
+        T_TRY(t_gemm_tn(gt(strct, 8, 0, t->d512a, 128, 0, c.g(pm.strct.k), 128, c.g(pm.strct.b), B, 8, 128), ss));
     }
     if ((rc = join(1))) return rc;
     if (st != caller) {
