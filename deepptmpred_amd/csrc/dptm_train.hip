@@ -435,6 +435,7 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
     const int wl = a.wlen;
     const TileCfg tc = t_tile_cfg(B, wl);
     const ConvArgs cf = conv_args(c, b, tok, B, seed, rt, tc);
+    PartPlan plan;       // the three launches' partial sums are added to the gradients by one launch after the last
     int rc;
     {
         // pooling and both TransformerBlocks backward: d(concat columns of this branch) -> d(x1), BN2 column sums
@@ -471,7 +472,7 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
         g.poolw = c.g(p.poolk);
         g.poolb = c.g(p.poolb);
         ProfScope ps(c, b * 6 + 3);
-        T_TRY(t_tb_bwd(f, g, wl, tc.NW, c.st));
+        T_TRY(t_tb_bwd(f, g, wl, tc.NW, &plan, c.st));
     }
     const ConvGrads cg{c.g(p.emb), c.g(p.pos), c.g(p.sck), c.g(p.scb), c.g(p.c3ak), c.g(p.c3ab), c.g(p.c3bk), c.g(p.c3bb)};
     // the input gradient of a BatchNorm needs the sums over the WHOLE batch, its parameter gradients this replica's share
@@ -481,7 +482,7 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
     }
     {
         ProfScope ps(c, b * 6 + 4);
-        T_TRY(t_conv_b_bwd(cf, cg, wl, tc.NW, c.st));
+        T_TRY(t_conv_b_bwd(cf, cg, wl, tc.NW, &plan, c.st));
     }
     if (t->ar_fn) {
         T_TRY(hipMemcpyAsync(c.s->bnsums_all, cf.bb1.own, 128 * sizeof(float), hipMemcpyDeviceToDevice, c.st));
@@ -489,7 +490,7 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
     }
     {
         ProfScope ps(c, b * 6 + 5);
-        T_TRY(t_conv_a_bwd(cf, cg, wl, tc.NW, c.st));
+        T_TRY(t_conv_a_bwd(cf, cg, wl, tc.NW, &plan, c.st));
     }
     return DPTM_OK;
 }

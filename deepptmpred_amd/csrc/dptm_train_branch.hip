@@ -811,7 +811,7 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
         const int b = o >> 10, rg = (o >> 6) & 15, lane = o & 63;
         const int k = 32 * (b >> 1) + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5), n = 32 * (b & 1) + (lane & 31);
         if (k >= ut.rows[u]) return;
-        src = part + (size_t)u * 4096 + o;
+        src = part + ut.off[u] + o;
         dst = ut.dst[u] + (size_t)k * ut.ld[u] + n;
     } else {
         int c = item - ut.n * 16, v = 0;
@@ -885,7 +885,7 @@ static hipError_t launch_bwd(const TbBwdArgs& a, int NW, int grid, hipStream_t s
     return hipGetLastError();
 }
 
-hipError_t t_tb_bwd(const TbBwdArgs& a, const TbGrads& g, int wlen, int NW, hipStream_t st) {
+hipError_t t_tb_bwd(const TbBwdArgs& a, const TbGrads& g, int wlen, int NW, PartPlan* plan, hipStream_t st) {
     if (a.n_sites == 0) return hipSuccess;
     if (!tile_ok(wlen, a.S, NW, a.n_sites, a.ntiles)) return hipErrorInvalidValue;
     const int grid = (int)(a.ntiles < kTbMaxParts ? a.ntiles : kTbMaxParts);
@@ -896,8 +896,11 @@ hipError_t t_tb_bwd(const TbBwdArgs& a, const TbGrads& g, int wlen, int NW, hipS
         default: e = launch_bwd<51>(a, NW, grid, st); break;
     }
     if (e != hipSuccess) return e;
-    PartUnits ut;
-    PartVecs vt;
+    // units 0 .. 23 and vectors 0 .. 29 of the plan (the convolution kernels append theirs)
+    PartUnits& ut = plan->units;
+    PartVecs& vt = plan->vecs;
+    ut = PartUnits();
+    vt = PartVecs();
     ut.n = kTbUnits;
     vt.n = kTbVecs;
     for (int i = 0; i < kTbVecs; ++i) {
@@ -926,7 +929,11 @@ hipError_t t_tb_bwd(const TbBwdArgs& a, const TbGrads& g, int wlen, int NW, hipS
     }
     vt.dst[kSPoolW] = g.poolw;
     vt.dst[kSPoolB] = g.poolb; vt.len[kSPoolB] = 1;
-    return t_reduce_parts(a.part, grid, ut, vt, st);
+    if (part_sums_deferred(a.ntiles)) return hipSuccess;
+    e = t_reduce_parts(a.part, grid, ut, vt, st);
+    ut.n = 0;
+    vt.n = 0;
+    return e;
 }
 
 }  // namespace dptm

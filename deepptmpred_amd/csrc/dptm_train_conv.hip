@@ -332,7 +332,7 @@ __global__ __launch_bounds__(512) void conv_b_fwd_kernel(ConvArgs p) {
 // conv_a_bwd: 4 units (conv3a taps, shortcut) | conv3a bias, shortcut bias | embedding rows [21][64] | position rows [W][64]
 constexpr int kCbVec = 3 * 4096;
 constexpr int kCaVec = 5 * 4096, kCaPos = kCaVec + 128;        // units 0..2 taps, 3 shortcut, 4 embedding table (rows 0..20)
-static_assert(kCaPos + kMaxW * 64 <= kTbPartStride, "the convolution kernels share the TransformerBlock kernel's partial buffer");
+static_assert(kCbVec + 64 <= kCbFloats && kCaPos + kMaxW * 64 <= kCaFloats && kMaxW <= kMaxWin, "regions of the partial buffer");
 
 // SHORT: the instance for tiles of fewer than eight wavefronts (small batches), see dw_unit
 template <int W, bool SHORT>
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(512) void conv_b_bwd_kernel(ConvArgs p) {
     float* own_b = bufB + wave * 32 * kLdsStride;
     float* mine_a = own_a + j * kLdsStride;
     float* mine_b = own_b + j * kLdsStride;
-    float* part = p.part + (size_t)blockIdx.x * kTbPartStride;
+    float* part = p.part + (size_t)blockIdx.x * kTbPartStride + kCbBase;
     for (int i = tid; i < 192; i += blockDim.x) vacc[i] = 0.f;
     bn_bwd_prepare(p.bb2, bb, tid, blockIdx.x == 0);
     {
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(512) void conv_a_bwd_kernel(ConvArgs p) {
     const int row = wave * 32 + j;
     float* own_b = bufB + wave * 32 * kLdsStride;
     float* mine_b = own_b + j * kLdsStride;
-    float* part = p.part + (size_t)blockIdx.x * kTbPartStride;
+    float* part = p.part + (size_t)blockIdx.x * kTbPartStride + kCaBase;
     for (int i = tid; i < 128; i += blockDim.x) vacc[i] = 0.f;
     bn_bwd_prepare(p.bb1, bb, tid, blockIdx.x == 0);
     bool first = true;
@@ -607,48 +607,54 @@ hipError_t t_conv_b_fwd(const ConvArgs& a, int wlen, int NW, hipStream_t st) {
     return e;
 }
 
-hipError_t t_conv_b_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW, hipStream_t st) {
+hipError_t t_conv_b_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW, PartPlan* plan, hipStream_t st) {
     if (a.n_sites == 0) return hipSuccess;
     if (!tile_ok(wlen, a.S, NW, a.n_sites, a.ntiles)) return hipErrorInvalidValue;
     hipError_t e;
     DPTM_CONV_DISPATCH_BWD(conv_b_bwd_kernel, conv_bwd_lds(NW), conv_bwd_lds(8), kTbMaxParts)
     if (e != hipSuccess) return e;
-    const int grid = (int)(a.ntiles < kTbMaxParts ? a.ntiles : kTbMaxParts);
-    PartUnits ut;
-    PartVecs vt;
-    ut.n = 3;
+    PartUnits& ut = plan->units;
+    PartVecs& vt = plan->vecs;
+    if (ut.n + 3 > kPartMaxUnits || vt.n + 1 > kPartMaxVecs) return hipErrorInvalidValue;
     for (int t = 0; t < 3; ++t) {
-        ut.dst[t] = g.c3bk + t * 4096;
-        ut.ld[t] = 64;
+        ut.dst[ut.n] = g.c3bk + t * 4096;
+        ut.off[ut.n] = kCbBase + t * 4096;
+        ut.ld[ut.n] = 64;
+        ut.rows[ut.n] = 64;
+        ++ut.n;
     }
-    vt.n = 1;
-    vt.dst[0] = g.c3bb; vt.off[0] = kCbVec; vt.len[0] = 64;
-    return t_reduce_parts(a.part, grid, ut, vt, st);
+    vt.dst[vt.n] = g.c3bb; vt.off[vt.n] = kCbBase + kCbVec; vt.len[vt.n] = 64;
+    ++vt.n;
+    if (part_sums_deferred(a.ntiles)) return hipSuccess;
+    const int grid = (int)(a.ntiles < kTbMaxParts ? a.ntiles : kTbMaxParts);
+    e = t_reduce_parts(a.part, grid, ut, vt, st);
+    ut.n = 0;
+    vt.n = 0;
+    return e;
 }
 
-hipError_t t_conv_a_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW, hipStream_t st) {
+hipError_t t_conv_a_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW, PartPlan* plan, hipStream_t st) {
     if (a.n_sites == 0) return hipSuccess;
     if (!tile_ok(wlen, a.S, NW, a.n_sites, a.ntiles)) return hipErrorInvalidValue;
     hipError_t e;
     DPTM_CONV_DISPATCH_BWD(conv_a_bwd_kernel, conv_bwd_lds(NW), conv_bwd_lds(8), kTbMaxParts)
     if (e != hipSuccess) return e;
     const int grid = (int)(a.ntiles < kTbMaxParts ? a.ntiles : kTbMaxParts);
-    PartUnits ut;
-    PartVecs vt;
-    ut.n = 5;
-    for (int t = 0; t < 3; ++t) {
-        ut.dst[t] = g.c3ak + t * 4096;
-        ut.ld[t] = 64;
+    PartUnits& ut = plan->units;
+    PartVecs& vt = plan->vecs;
+    if (ut.n + 5 > kPartMaxUnits || vt.n + 3 > kPartMaxVecs) return hipErrorInvalidValue;
+    float* const unit_dst[5] = {g.c3ak, g.c3ak + 4096, g.c3ak + 2 * 4096, g.sck, g.emb};
+    for (int t = 0; t < 5; ++t) {
+        ut.dst[ut.n] = unit_dst[t];
+        ut.off[ut.n] = kCaBase + t * 4096;
+        ut.ld[ut.n] = 64;
+        ut.rows[ut.n] = t == 4 ? kCodes : 64;       // embedding table [kCodes][64]: only the unit's first kCodes rows exist
+        ++ut.n;
     }
-    ut.dst[3] = g.sck;
-    ut.ld[3] = 64;
-    ut.dst[4] = g.emb;          // [kCodes][64]: only the unit's first kCodes rows exist
-    ut.ld[4] = 64;
-    ut.rows[4] = kCodes;
-    vt.n = 3;
-    vt.dst[0] = g.c3ab; vt.off[0] = kCaVec; vt.len[0] = 64;
-    vt.dst[1] = g.scb; vt.off[1] = kCaVec + 64; vt.len[1] = 64;
-    vt.dst[2] = g.pos; vt.off[2] = kCaPos; vt.len[2] = wlen * 64;
+    vt.dst[vt.n] = g.c3ab; vt.off[vt.n] = kCaBase + kCaVec; vt.len[vt.n] = 64; ++vt.n;
+    vt.dst[vt.n] = g.scb; vt.off[vt.n] = kCaBase + kCaVec + 64; vt.len[vt.n] = 64; ++vt.n;
+    vt.dst[vt.n] = g.pos; vt.off[vt.n] = kCaBase + kCaPos; vt.len[vt.n] = wlen * 64; ++vt.n;
+    // every backward launch of the branch has left its partial sums: one launch adds them to the gradients
     return t_reduce_parts(a.part, grid, ut, vt, st);
 }
 

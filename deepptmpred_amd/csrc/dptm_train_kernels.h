@@ -193,7 +193,14 @@ hipError_t t_tb_fwd(const TbFwdArgs& a, int wlen, int NW, hipStream_t st);
 //   24 weight-gradient units of 4096 (MFMA accumulator order) | 30 vectors of 64
 constexpr int kTbUnits = 24;
 constexpr int kTbVecs = 30;
-constexpr int kTbPartStride = kTbUnits * 4096 + kTbVecs * 64 + 128;   // 100,352: a multiple of 256
+constexpr int kTbPartFloats = kTbUnits * 4096 + kTbVecs * 64 + 128;   // 100,352: a multiple of 256
+// A workgroup's partial buffer has a region per backward launch of the branch -- TransformerBlocks | second convolution
+// (3 tap units, bias) | first convolution (3 tap units, shortcut, embedding table; two bias vectors; position table) --
+// so that ONE launch sums all of them after the last backward kernel.
+constexpr int kMaxWin = 51;
+constexpr int kCbBase = kTbPartFloats, kCbFloats = 3 * 4096 + 256;
+constexpr int kCaBase = kCbBase + kCbFloats, kCaFloats = 5 * 4096 + 256 + kMaxWin * 64;
+constexpr int kTbPartStride = (kCaBase + kCaFloats + 255) / 256 * 256;
 constexpr int kTbMaxParts = 256;
 struct TbBwdArgs {
     const f32x4_tr* P;
@@ -222,25 +229,38 @@ struct TbGrads {
     float *w1[2], *b1[2], *w2[2], *b2[2], *ln1g[2], *ln1b[2], *ln2g[2], *ln2b[2];
     float *poolw, *poolb;
 };
-hipError_t t_tb_bwd(const TbBwdArgs& a, const TbGrads& g, int wlen, int NW, hipStream_t st);
+struct PartPlan;       // below: what the branch's backward launches leave to be summed
+hipError_t t_tb_bwd(const TbBwdArgs& a, const TbGrads& g, int wlen, int NW, PartPlan* plan, hipStream_t st);
 
 // Sum of the workgroups' partial buffers (stride kTbPartStride) into gradient tensors: weight-gradient units
 // (unit u at float u*4096 of a buffer, MFMA accumulator order; element (k, n) goes to dst[u][k*ld[u] + n]) and
 // plain vectors (len floats at float off of a buffer).  Results are ADDED to the destinations.
+constexpr int kPartMaxUnits = 32, kPartMaxVecs = 36;
 struct PartUnits {
     int n;
-    float* dst[24];
-    int ld[24];
-    int rows[24];          // rows k >= rows[u] of a unit are dropped (64: the whole unit)
+    float* dst[kPartMaxUnits];
+    int off[kPartMaxUnits];     // float offset of the unit inside a buffer
+    int ld[kPartMaxUnits];
+    int rows[kPartMaxUnits];    // rows k >= rows[u] of a unit are dropped (64: the whole unit)
     PartUnits() : n(0) {
-        for (int i = 0; i < 24; ++i) { dst[i] = nullptr; ld[i] = 64; rows[i] = 64; }
+        for (int i = 0; i < kPartMaxUnits; ++i) { dst[i] = nullptr; off[i] = i * 4096; ld[i] = 64; rows[i] = 64; }
     }
 };
 struct PartVecs {
     int n;
-    float* dst[32];
-    int off[32], len[32];
+    float* dst[kPartMaxVecs];
+    int off[kPartMaxVecs], len[kPartMaxVecs];
+    PartVecs() : n(0) {}
 };
+// What the backward launches of one branch leave to be summed: each launch appends its units and vectors.  A step with a
+// tile per workgroup is a chain of short launches, and ONE summing launch after the last backward kernel (the first
+// convolution's) keeps two launches off that chain; with many tiles per workgroup every kernel's sums are added right
+// behind it, where the launch overlaps with the other branches instead of ending the step (part_sums_deferred).
+struct PartPlan {
+    PartUnits units;
+    PartVecs vecs;
+};
+inline bool part_sums_deferred(int64_t ntiles) { return ntiles <= kTbMaxParts; }
 hipError_t t_reduce_parts(const float* part, int nparts, const PartUnits& u, const PartVecs& v, hipStream_t st);
 
 // ---- fused embedding + residual convolution block (dptm_train_conv.hip); transposed images of the convolution
@@ -276,8 +296,8 @@ struct ConvGrads {
 };
 hipError_t t_conv_a_fwd(const ConvArgs& a, int wlen, int NW, hipStream_t st);   // tokens -> s, a1, stats1
 hipError_t t_conv_b_fwd(const ConvArgs& a, int wlen, int NW, hipStream_t st);   // a1 -> a2, stats2
-hipError_t t_conv_b_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW, hipStream_t st);   // dx1 -> dz1, conv3b / BN2 gradients
-hipError_t t_conv_a_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW, hipStream_t st);   // dz1, dx1 -> conv3a / shortcut / BN1 / embedding gradients
+hipError_t t_conv_b_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW, PartPlan* plan, hipStream_t st);   // dx1 -> dz1, conv3b / BN2 gradients
+hipError_t t_conv_a_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW, PartPlan* plan, hipStream_t st);   // dz1, dx1 -> conv3a / shortcut / BN1 / embedding gradients
 
 
 // ---- per-site dense layers for small batches (dptm_train_site.hip)
