@@ -176,6 +176,18 @@ def keras_model_layers(spec: ModelSpec = DEFAULT_SPEC) -> List[str]:
     return sorted(finished, key=lambda n: (-depth[n], index[n]))
 
 
+def keras_weight_order(spec: ModelSpec = DEFAULT_SPEC) -> List[str]:
+    """Canonical tensor names in the order of Keras' ``model.weights`` / ``model.get_weights()`` for the
+    model of model.py:210: layer by layer in ``model.layers`` order (``keras_model_layers``: by depth, so
+    the three Embedding tables come first), and inside a layer trainable before non-trainable variables
+    in attribute-tracking order -- BatchNormalization gamma, beta, moving mean, moving variance; a
+    TransformerBlock query, key, value, combine, the two FFN layers, the two LayerNormalizations."""
+    by_name = dict(keras_layer_table(spec))
+    order = [canon for ln in keras_model_layers(spec) if ln in by_name for _, canon in by_name[ln]]
+    assert sorted(order) == sorted(n for n, _ in tensor_table(spec))
+    return order
+
+
 def _split_suffix(name: str) -> Tuple[str, int]:
     """'dense_12' -> ('dense', 12); 'dense' -> ('dense', 0)."""
     head, sep, tail = name.rpartition("_")

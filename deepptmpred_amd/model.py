@@ -15,8 +15,8 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 from . import _native
-from .spec import (DEFAULT_SPEC, LETTER_CODES, PAD_CODE, ModelSpec, load_flat, pack_blob,
-                   save_flat, synthetic_weights, tensor_table, unpack_blob)
+from .spec import (DEFAULT_SPEC, LETTER_CODES, PAD_CODE, ModelSpec, keras_initial_weights, load_flat, pack_blob,
+                   save_flat, tensor_table, unpack_blob)
 
 
 def _as_tokens(a, width: int, name: str) -> np.ndarray:
@@ -269,13 +269,22 @@ class Model:
                 if n.endswith((".sc_k", ".c3a_k", ".c3b_k")) or n in ("t1.k", "t2.k")]
 
     def get_weights(self) -> List[np.ndarray]:
+        """``model.get_weights()``: every array of the model in Keras' ``model.weights`` order for the
+        graph of model.py:210 (depth-sorted layers: the three ``[21, 64]`` embedding tables first).
+        ``named_weights()`` gives the same arrays by canonical name."""
         if getattr(self, "_dirty", False):
             self._pull_trained_weights()
             self._dirty = False
-        return [self._weights[n].copy() for n, _ in tensor_table(self.spec)]
+        return [self._weights[n].copy() for n in self._keras_order()]
+
+    def _keras_order(self) -> List[str]:
+        from .keras_h5 import keras_weight_order
+        return keras_weight_order(self.spec)
 
     def set_weights(self, arrays: Sequence[np.ndarray]) -> None:
-        table = tensor_table(self.spec)
+        """``model.set_weights(list)`` with the list in the order ``get_weights`` returns."""
+        shapes = dict(tensor_table(self.spec))
+        table = [(n, shapes[n]) for n in self._keras_order()]
         if len(arrays) != len(table):
             raise ValueError(f"set_weights: expected {len(table)} arrays, got {len(arrays)}")
         new = {}
@@ -295,7 +304,11 @@ class Model:
         self._dirty = False
 
     def named_weights(self) -> Dict[str, np.ndarray]:
-        return dict(self._weights)
+        """name -> array in the canonical order of ``spec.tensor_table`` (the order of the C ABI's blob)."""
+        if getattr(self, "_dirty", False):
+            self._pull_trained_weights()
+            self._dirty = False
+        return {n: self._weights[n] for n, _ in tensor_table(self.spec)}
 
     def save(self, filepath: str) -> None:
         """``model.save(path)``: a Keras-2 HDF5 weight tree for ``*.h5`` / ``*.hdf5`` paths
@@ -337,9 +350,10 @@ def load_model(filepath, custom_objects=None, compile=True, device: int = 0) -> 
 
 
 def create_ptm_model(config=None, seed: int = 0, device: int = 0) -> Model:
-    """Stand-in for ``create_ptm_model(config)`` (model.py:143): a freshly initialised
-    model.  ``config`` may carry the reference's attribute names; only the reference
-    dimensions are supported."""
+    """Stand-in for ``create_ptm_model(config)`` (model.py:143): a freshly initialised model in the
+    state Keras' default initialisers give it (``spec.keras_initial_weights``: Glorot kernels, zero
+    biases, identity BatchNormalization, head bias [0.1, 1.0]).  ``config`` may carry the reference's
+    attribute names; only the reference dimensions are supported."""
     spec = DEFAULT_SPEC
     if config is not None:
         for attr in ("embed_dim", "num_heads", "ff_dim", "esm_dim", "struct_feature_dim", "max_features"):
@@ -347,4 +361,4 @@ def create_ptm_model(config=None, seed: int = 0, device: int = 0) -> Model:
                 raise ValueError(f"create_ptm_model: {attr}={getattr(config, attr)} is not supported")
         if hasattr(config, "window_sizes") and tuple(config.window_sizes) != spec.window_sizes:
             raise ValueError("create_ptm_model: window_sizes must be [21, 33, 51]")
-    return Model(synthetic_weights(seed, spec), spec, device)
+    return Model(keras_initial_weights(seed, spec), spec, device)

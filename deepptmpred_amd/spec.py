@@ -239,6 +239,34 @@ def synthetic_weights(seed: int = 7, spec: ModelSpec = DEFAULT_SPEC) -> Dict[str
     return out
 
 
+def keras_initial_weights(seed: int = 0, spec: ModelSpec = DEFAULT_SPEC) -> Dict[str, np.ndarray]:
+    """The state ``create_ptm_model(config)`` starts from (model.py:143-210 under the Keras-2 default
+    initialisers): ``Embedding`` tables uniform(-0.05, 0.05) (model.py:157), position tables and every
+    Dense / Conv1D kernel Glorot-uniform (model.py:22-27; limit sqrt(6 / (fan_in + fan_out)) with the
+    kernel width counted into both fans), all biases zero, BatchNormalization gamma 1 / beta 0 /
+    moving mean 0 / moving variance 1, LayerNormalization gamma 1 / beta 0, and the head bias
+    ``Constant([0.1, 1.0])`` (model.py:207-208).  The values come from numpy's ``default_rng(seed)``,
+    not TensorFlow's generator: the distribution is the reference's, the draws are not."""
+    rng = np.random.default_rng(seed)
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in tensor_table(spec):
+        leaf = name.rsplit(".", 1)[1]
+        if leaf in ("gamma", "var", "ln1_g", "ln2_g"):
+            a = np.ones(shape)
+        elif leaf == "emb":
+            a = rng.uniform(-0.05, 0.05, shape)
+        elif len(shape) == 1:      # biases, beta, moving mean
+            a = np.zeros(shape)
+        else:
+            rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+            lim = np.sqrt(6.0 / (shape[-2] * rf + shape[-1] * rf))
+            a = rng.uniform(-lim, lim, shape)
+        out[name] = a.astype(np.float32)
+    if spec.n_classes == 2:
+        out["head.b"] = np.array([0.1, 1.0], dtype=np.float32)
+    return out
+
+
 def synthetic_inputs(n: int, seed: int = 1234, spec: ModelSpec = DEFAULT_SPEC,
                      pad_fraction: float = 0.05):
     """Synthetic sites shaped like real ones: residue codes 0..19 with edge

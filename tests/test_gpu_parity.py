@@ -320,3 +320,41 @@ def test_predict_all_types_shares_one_upload(weights):
         assert np.array_equal(res[k], m.predict(x))
         m.close()
     assert predict_all_types({}, x) == {}
+
+
+def test_all_seventeen_weight_sets_vs_oracle():
+    """The 17-type sweep of predict.py:119-137 at the weight seeds the proteome configuration names
+    (100 ... 116): every model resident at once, ONE upload of the sites shared by all types
+    (``predict_all_types``), every type's probabilities against the oracle."""
+    from deepptmpred_amd.sharding import predict_all_types
+    types = list(spec.PTM_AA_MAP)
+    assert len(types) == 17
+    ws = {t: spec.synthetic_weights(100 + i) for i, t in enumerate(types)}
+    ms = {t: Model(w) for t, w in ws.items()}
+    x = spec.synthetic_inputs(500, 1717)
+    res = predict_all_types(ms, x, pass_sites=384)            # two passes, ragged tail
+    worst = 0.0
+    for t in types:
+        err = float(np.abs(res[t] - oracle(ws[t], x)).max())
+        worst = max(worst, err)
+        assert err < TOL, (t, err)
+        assert np.abs(res[t].sum(axis=1) - 1).max() < 1e-6
+        ms[t].close()
+    print("17 types, max abs err", worst)
+    # the weight sets are distinct models: no two types give the same column
+    cols = np.stack([res[t][:, 1] for t in types])
+    assert np.unique(cols.round(6), axis=0).shape[0] == 17
+
+
+def test_fresh_model_predicts_like_the_oracle():
+    """``create_ptm_model`` (model.py:143-210) starts from the Keras initial state; scoring with it
+    before any training equals the oracle on the same weights, raw structure rows included."""
+    from deepptmpred_amd.model import create_ptm_model
+    m = create_ptm_model(seed=11)
+    w = m.named_weights()
+    assert w["head.b"].tolist() == [np.float32(0.1), np.float32(1.0)]
+    x = spec.synthetic_inputs(300, 55)
+    p = m.predict(x)
+    ref = oracle(w, x)
+    assert np.isfinite(p).all() and np.abs(p - ref).max() < TOL
+    m.close()

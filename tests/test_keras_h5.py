@@ -103,7 +103,8 @@ def test_keras_checkpoint_roundtrip_through_model(tmp_path):
     back = read_keras_h5(p)
     assert all(np.array_equal(back[k], w[k]) for k in w)
     m = load_model(p, custom_objects={"PositionEmbedding": None, "focal_loss": None})
-    for a, (name, _) in zip(m.get_weights(), spec.tensor_table()):
+    from deepptmpred_amd.keras_h5 import keras_weight_order
+    for a, name in zip(m.get_weights(), keras_weight_order()):
         assert np.array_equal(a, w[name])
     # a save_weights-style file: the same tree at the root
     f = H5File(p)
