@@ -113,7 +113,8 @@ def issue_bound(precision: str, sites_per_launch: float, avg_launch_s: float):
             continue
         peak = N_SIMD * PEAK_CLOCK_GHZ * 1e9 / rec["issue_cycles_per_site"]
         achieved = sites_per_launch / avg_launch_s
-        return {"bound": "valu", "kernel": KERNEL_NAME[precision], "achieved": achieved, "peak": peak,
+        return {"kind": "issue-slot budget of the kernel's own instruction mix (a utilisation diagnostic, not a roofline)",
+                "kernel": KERNEL_NAME[precision], "achieved": achieved, "peak": peak,
                 "unit": "sites/s", "frac": achieved / peak,
                 "issue_cycles_per_site": rec["issue_cycles_per_site"],
                 "valu_insts_per_site": rec["valu_insts_per_site"], "mfma_insts_per_site": rec["mfma_insts_per_site"],
@@ -292,6 +293,28 @@ def cpu_baseline(weights, budget_s: float = 12.0):
             "grid": grid, "host_cpu_count": os.cpu_count()}
 
 
+def cpu_train_baseline(batch: int = 64, budget_s: float = 10.0):
+    """The training step of oracle/train_ref.py (torch autograd + AdamW, fp32, dropout on) on the host cores:
+    forward in training mode, loss, backward and the optimizer update per step, batch 64 (config.py:56)."""
+    from deepptmpred_amd import spec
+    from oracle.train_ref import TrainRef
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    ref = TrainRef(spec.synthetic_weights(7), torch.float32)
+    x = spec.synthetic_inputs(batch, 99)
+    y = (np.random.default_rng(5).random(batch) < 0.042).astype(np.int64)
+    y[0] = 1                                        # at least one positive, as the class weights assume
+    ref.step(x, y, seed=0)                          # warm-up
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < 3 or (time.perf_counter() - t0 < budget_s and steps < 200):
+        ref.step(x, y, seed=steps + 1)
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": batch * steps / dt, "unit": "sites/s", "ms_per_step": dt / steps * 1e3, "cores": threads, "kind": "port",
+            "sample": f"{steps} steps of batch {batch}, torch-CPU fp32 autograd restatement of the training step, {dt:.1f} s"}
+
+
 # ------------------------------------------------------------------------------------ training step
 
 def measure_train(R: Ranks, batch: int, steps: int, warmup: int) -> dict:
@@ -382,8 +405,10 @@ def measure_fit(R: Ranks, sites: int = 6400, batch: int = 64) -> dict:
 
 def train_main(args, R: Ranks) -> None:
     m = measure_train(R, args.batch, args.steps, args.warmup)
+    cpu = cpu_train_baseline(min(args.batch, 4096)) if R.rank == 0 and R.world == 1 and not args.no_cpu_baseline else None
     if R.rank == 0:
         print(json.dumps({
+            **({"cpu_baseline": cpu} if cpu else {}),
             "metric": "training sites/sec (fwd+bwd+all-reduce+AdamW)", "value": m["sites_per_s"], "unit": "sites/s",
             "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -400,7 +425,8 @@ def train_main(args, R: Ranks) -> None:
 
 # ------------------------------------------------------------------------------------ 17-type sweep
 
-def measure_sweep(R: Ranks, T: int, n: int, steps: int, warmup: int, precision: str, x=None) -> dict:
+def measure_sweep(R: Ranks, T: int, n: int, steps: int, warmup: int, precision: str, x=None, streamed_sites: int = 262144,
+                  warm_sites: int = 0) -> dict:
     """The same resident sites scored by T weight sets (every PTM type has its own model,
     predict.py:119-137).  Sites are sharded over ranks, every rank holds all T models (6.5 MB each),
     inputs are read T times from HBM and never re-uploaded.  Counts (site, type) scorings per second;
@@ -423,17 +449,30 @@ def measure_sweep(R: Ranks, T: int, n: int, steps: int, warmup: int, precision: 
         for m, o in zip(models.values(), outs):
             m.scorer.score_device(ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], n, o.data_ptr(), stream)
 
+    if warm_sites:      # workspaces and first launches of every model on a few sites instead of a whole untimed step
+        for m, o in zip(models.values(), outs):
+            m.scorer.score_device(ptrs[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4], min(n, warm_sites), o.data_ptr(), stream)
     elapsed = R.timed(step, steps, warmup)
+    # every (site, type) of the run: finite probabilities that sum to one
+    worst_row = 0.0
     for o in outs:
-        chk = o[:: max(1, n // 1024)].cpu().numpy()
-        assert np.isfinite(chk).all() and np.abs(chk.sum(axis=1) - 1).max() < 1e-5
-    # different weight sets must give different answers (the models are really distinct)
-    assert T == 1 or float((outs[0][:1024] - outs[-1][:1024]).abs().max().item()) > 0
+        assert bool(torch.isfinite(o).all().item())
+        worst_row = max(worst_row, float((o.sum(dim=1) - 1).abs().max().item()))
+    assert worst_row < 1e-5, worst_row
+    # different weight sets must give different answers (the models are really distinct): no two types agree
+    distinct = True
+    for a in range(T):
+        for b in range(a + 1, T):
+            distinct &= float((outs[a][:4096] - outs[b][:4096]).abs().max().item()) > 1e-4
+    assert distinct
 
     streamed = None
-    if R.rank == 0:
-        m = min(n, 262144)
-        hx = spec.synthetic_inputs(m, 77)
+    if R.rank == 0 and streamed_sites:
+        m = min(n, streamed_sites)
+        block = spec.synthetic_inputs(min(m, 262144), 77)
+        # larger host sets are the 262,144-site block cycled (generating 66 GB of random rows on the host would take
+        # longer than scoring them)
+        hx = block if m <= 262144 else [np.tile(a, (-(-m // 262144), 1))[:m] for a in block]
         predict_all_types(models, [a[:4096] for a in hx])            # warm-up: pinned buffers, first launches
         t1 = time.perf_counter()
         res = predict_all_types(models, hx)
@@ -449,12 +488,13 @@ def measure_sweep(R: Ranks, T: int, n: int, steps: int, warmup: int, precision: 
             "site_types_per_s": value, "sites_per_s_all_types": value / T,
             "tflops_per_gpu": value / R.world * FLOPS_PER_SITE / 1e12,
             "frac_of_mfma_peak": value / R.world * FLOPS_PER_SITE / 1e12 / PEAK_MFMA[precision],
+            "checked": {"site_types": n * T, "finite": True, "max_row_sum_err": worst_row, "types_pairwise_distinct": distinct},
             "streamed_from_host": streamed}
 
 
 def sweep_main(args, R: Ranks) -> None:
     T, n = args.types, args.sites
-    m = measure_sweep(R, T, n, args.steps, args.warmup, args.precision)
+    m = measure_sweep(R, T, n, args.steps, args.warmup, args.precision, None, args.streamed_sites, 4096)
     if R.rank == 0:
         print(json.dumps({
             "metric": "windows x PTM types scored/sec", "value": m["site_types_per_s"], "unit": "site-types/s",
@@ -610,6 +650,8 @@ def main() -> None:
     ap.add_argument("--train", action="store_true",
                     help="measure the training step (BASELINE config 5) instead of scoring")
     ap.add_argument("--batch", type=int, default=64, help="--train: sites per GPU per step")
+    ap.add_argument("--streamed-sites", type=int, default=262144,
+                    help="--types: sites of the host-array leg (NumPy in, NumPy out; 0 skips it)")
     ap.add_argument("--proteome", action="store_true",
                     help="score many synthetic proteins per call with device-side window assembly instead")
     ap.add_argument("--proteins", type=int, default=20000, help="--proteome: proteins per GPU per step")
@@ -660,6 +702,8 @@ def main() -> None:
     # beside the headline, never as `value`
     variants = {}
     if rank == 0 and world == 1 and not args.no_variants:
+        ref_out = out.clone()                      # the headline mode's probabilities of the same sites
+        bound_vs_f32 = {"f32": 1e-4, "f16x3": 1e-4, "f16": 1e-2, "bf16": 6e-2}   # the modes' test bounds
         for mode in ("f32", "f16x3", "f16", "bf16"):
             if mode == args.precision:
                 continue
@@ -675,14 +719,28 @@ def main() -> None:
             step()
             vp = sc.profile_end()
             torch.cuda.synchronize()
+            # every site of the run: finite, rows sum to one, within the mode's bound of the headline mode's answer
+            finite = bool(torch.isfinite(out).all().item())
+            row_err = float((out.sum(dim=1) - 1).abs().max().item())
+            diff = float((out - ref_out).abs().max().item())
+            bound = max(bound_vs_f32[mode], bound_vs_f32[args.precision])
+            assert finite and row_err < 1e-5 and diff < bound, (mode, finite, row_err, diff)
             v_ms, v_launches = vp["branch51"]
+            v_avg_s = v_ms * 1e-3 / max(v_launches, 1)
             v_tf = n * FLOPS_BRANCH[51] / (v_ms * 1e-3) / 1e12 if v_ms > 0 else 0.0
-            variants[mode] = {"sites_per_s_one_gpu": n / dt, "branch51_avg_launch_ms": v_ms / max(v_launches, 1),
-                              "branch51_tflops_algorithmic": v_tf, "branch51_frac_of_mfma_peak": v_tf / PEAK_MFMA[mode]}
-            ib = issue_bound(mode, n / max(v_launches, 1), v_ms * 1e-3 / max(v_launches, 1))
-            if ib:
-                variants[mode]["roofline"] = ib
+            variants[mode] = {"sites_per_s_one_gpu": n / dt, "branch51_avg_launch_ms": v_avg_s * 1e3,
+                              "checked": {"sites": n, "finite": finite, "max_row_sum_err": row_err,
+                                          "max_abs_diff_vs_" + args.precision: diff, "bound": bound},
+                              "roofline": {"bound": "mfma", "kernel": KERNEL_NAME[mode], "achieved": v_tf,
+                                           "peak": PEAK_MFMA[mode], "unit": "TFLOP/s", "frac": v_tf / PEAK_MFMA[mode],
+                                           "traffic": measured_traffic(mode, n / max(v_launches, 1))[0],
+                                           "avg_launch_ms": v_avg_s * 1e3, "sites_per_launch": n / max(v_launches, 1),
+                                           "flops_per_site": FLOPS_BRANCH[51]}}
+            ib = issue_bound(mode, n / max(v_launches, 1), v_avg_s)
+            if ib:      # a utilisation diagnostic from the kernel's own instruction counts, not a roofline
+                variants[mode]["issue_budget"] = ib
         sc.set_precision(args.precision)
+        del ref_out
     R.barrier()
 
     # configs 4 and 5 and the host / proteome forms, on one GPU, beside the headline (never `value`)
@@ -701,12 +759,16 @@ def main() -> None:
         ns = min(n, 262144)
         xs = [t[:ns] for t in x]
         extras["sweep"] = guarded(measure_sweep, R, 17 if n >= 262144 else 3, ns, 2, 1, args.precision, xs)
+        # config 4 at one GPU's resident million: all 17 weight sets over every site of the headline run, one step
+        extras["sweep_1m"] = guarded(measure_sweep, R, 17 if n >= 262144 else 3, n, 1, 0, args.precision, x, 0, 4096)
         del x, xs, out
         torch.cuda.empty_cache()
         extras["train"] = {"batch64": guarded(measure_train, R, 64, 50, 10),
                            "batch8192": guarded(measure_train, R, 8192, 5, 2) if n >= 262144 else None,
                            "batch32768": guarded(measure_train, R, 32768, 3, 1) if n >= 262144 else None,
                            "fit_batch64": guarded(measure_fit, R, 6400 if n >= 262144 else 640)}
+        if not args.no_cpu_baseline:
+            extras["train"]["cpu_baseline"] = guarded(cpu_train_baseline, 64, 8.0 if n >= 262144 else 2.0)
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -740,11 +802,8 @@ def main() -> None:
             "kernel_ms_total": round(total_kernel_ms, 3),
         }
         ib = issue_bound(args.precision, sites_per_launch, avg_s)
-        if ib and args.precision != "f32":       # the half-precision kernels are issue-bound: the matrix-peak fraction stays beside it
-            line["roofline_mfma"] = line["roofline"]
-            line["roofline"] = dict(ib, traffic=traffic, avg_launch_ms=avg_s * 1e3, sites_per_launch=sites_per_launch)
-        elif ib:                                 # fp32: matrix-bound; the issue-slot budget (matrix + vector) beside it
-            line["roofline_issue"] = ib
+        if ib:                                   # matrix + vector issue slots of the kernel's own instruction mix, beside the roofline
+            line["issue_budget"] = ib
         if variants:
             line["variants"] = variants
         line.update(extras)

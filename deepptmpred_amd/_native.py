@@ -34,6 +34,7 @@ EXPORTS = (
     "dptm_trainer_get_weights", "dptm_trainer_get_grads", "dptm_trainer_get_proba",
     "dptm_trainer_get_optimizer_state", "dptm_trainer_set_optimizer_state",
     "dptm_trainer_profile_begin", "dptm_trainer_profile_end", "dptm_trainer_loss_buffer", "dptm_trainer_stream",
+    "dptm_trainer_stage_loss", "dptm_trainer_lanes",
     "dptm_trainer_last_error", "dptm_trainer_set_allreduce", "dptm_sasa", "dptm_sasa_last_error",
 )
 
@@ -179,6 +180,10 @@ def load_library() -> C.CDLL:
     lib.dptm_trainer_set_optimizer_state.argtypes = [vp, f32p, f32p, i64]
     lib.dptm_trainer_loss_buffer.restype = C.c_int
     lib.dptm_trainer_loss_buffer.argtypes = [vp, C.POINTER(vp)]
+    lib.dptm_trainer_stage_loss.restype = C.c_int
+    lib.dptm_trainer_stage_loss.argtypes = [vp, C.POINTER(i64), vp]
+    lib.dptm_trainer_lanes.restype = C.c_int
+    lib.dptm_trainer_lanes.argtypes = [vp, C.POINTER(C.c_int32)]
     lib.dptm_trainer_stream.restype = C.c_int
     lib.dptm_trainer_stream.argtypes = [vp, C.POINTER(vp)]
     lib.dptm_trainer_profile_begin.restype = C.c_int
@@ -450,6 +455,20 @@ class Trainer:
         p = C.c_void_p()
         _check_t(self._lib, self._lib.dptm_trainer_loss_buffer(self._h, C.byref(p)), "dptm_trainer_loss_buffer")
         return int(p.value)
+
+    def stage_loss(self, stream=0) -> int:
+        """Copies the step's loss into the spare float of the gradient buffer (in stream order) and returns that
+        float's index: the one gradient all-reduce of a data-parallel step then sums the loss shares as well."""
+        slot = C.c_int64(-1)
+        _check_t(self._lib, self._lib.dptm_trainer_stage_loss(self._h, C.byref(slot), C.c_void_p(stream or None)),
+                 "dptm_trainer_stage_loss")
+        return int(slot.value)
+
+    def lanes_independent(self) -> int:
+        """How many of the step's four streams sit on hardware queues of their own (4 = all concurrent)."""
+        v = C.c_int32(0)
+        _check_t(self._lib, self._lib.dptm_trainer_lanes(self._h, C.byref(v)), "dptm_trainer_lanes")
+        return int(v.value)
 
     def stream(self) -> int:
         """Handle (hipStream_t) of the stream the step's main lane runs on; work enqueued on it and calls that pass

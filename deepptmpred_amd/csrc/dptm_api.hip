@@ -811,6 +811,11 @@ int dptm_set_precision(dptm_handle* h, int mode) try {
         int rc = build_half_images(h);
         if (rc) return rc;
     }
+    if (mode != kModeF32) {
+        // kernel attributes now, not at the mode's first launch (which may sit inside a caller's graph capture)
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(prepare_kernels_h(mode));
+    }
     h->precision = mode;
     return DPTM_OK;
 } catch (...) {

@@ -59,5 +59,6 @@ struct AssembleArgs {
 };
 hipError_t launch_assemble(const AssembleArgs& a, hipStream_t st);
 hipError_t prepare_kernels();
+hipError_t prepare_kernels_h(int mode);   // LDS opt-in of the half-precision branch kernels of one mode
 
 }  // namespace dptm

@@ -876,10 +876,9 @@ hipError_t launch_dense_h(int mode, const DenseArgs& a, int epi, const void* whi
 
 static constexpr size_t kBranchLdsH = 2 * (size_t)kRegionB + kTileRows * sizeof(float) + kVecsF4 * 16 + 13 * 2 * 16;
 
+// the LDS opt-in of one instance on the current device (per device: remembered for every device of this process)
 template <int W, int MODE>
-static hipError_t launch_branch_h_t(const float* params, const void* whi, const void* wlo, const uint8_t* tok, int64_t n,
-                                    float* out, int ldo, int col_off, hipStream_t st) {
-    // the LDS opt-in is per device: remember which devices of this process have it
+static hipError_t branch_h_opt_in() {
     static bool attr_done_dev[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -890,6 +889,32 @@ static hipError_t launch_branch_h_t(const float* params, const void* whi, const 
         if (e != hipSuccess) return e;
         attr_done = true;
     }
+    return hipSuccess;
+}
+
+template <int MODE>
+static hipError_t branch_h_opt_in_mode() {
+    hipError_t e = branch_h_opt_in<21, MODE>();
+    if (e == hipSuccess) e = branch_h_opt_in<33, MODE>();
+    if (e == hipSuccess) e = branch_h_opt_in<51, MODE>();
+    return e;
+}
+
+// Per-device kernel attributes of one half-precision mode ahead of its first launch, so that no launch -- one under a
+// caller's graph capture, say -- has to set them.
+hipError_t prepare_kernels_h(int mode) {
+    switch (mode) {
+        case kModeBF16: return branch_h_opt_in_mode<kModeBF16>();
+        case kModeF16: return branch_h_opt_in_mode<kModeF16>();
+        case kModeF16X3: return branch_h_opt_in_mode<kModeF16X3>();
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int W, int MODE>
+static hipError_t launch_branch_h_t(const float* params, const void* whi, const void* wlo, const uint8_t* tok, int64_t n,
+                                    float* out, int ldo, int col_off, hipStream_t st) {
+    if (hipError_t e = branch_h_opt_in<W, MODE>(); e != hipSuccess) return e;
     constexpr int S = kTileRows / W;
     const int64_t blocks = (n + S - 1) / S;
     if (blocks == 0) return hipSuccess;

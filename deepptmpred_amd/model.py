@@ -232,33 +232,38 @@ class Model:
         hist = History()
         lr = trainer.optimizer.learning_rate
         y_labels = labels_from_targets(y)         # one array for all epochs: the device copy of the data set is kept
-        for epoch in range(int(epochs)):
-            for cb in cbs:
-                lr = cb.on_epoch_begin(epoch, lr)
-            trainer = self._trainer(batch_size)       # a callback may have replaced the weights
-            h1 = trainer.fit(x, y_labels, batch_size, 1, shuffle, lambda _e, _lr, _v=lr: _v, seed=epoch, verbose=0,
-                             keep_resident=True)
-            self._dirty = True
-            logs = {"loss": h1["loss"][0], "lr": lr}
-            if validation_data is not None:
-                vx, vy = validation_data
-                vl = labels_from_targets(vy)
-                p = self.predict(vx)
-                reg = sum(float(self.spec.weight_decay) * float(np.sum(np.square(self._weights[n].astype(np.float64))))
-                          for n in self._l2_names())
-                logs["val_loss"] = balanced_bce(p, vl) + reg
-                logs["val_accuracy"] = float(np.mean(np.argmax(p, axis=1) == vl))
-                logs["val_auc"] = roc_auc(vl, p[:, 1])
-            for k, v in logs.items():
-                hist.setdefault(k, []).append(v)
-            if verbose:
-                print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4g" % kv for kv in logs.items()))
-            for cb in cbs:
-                cb.on_epoch_end(epoch, logs)
-            if any(cb.stop_training for cb in cbs):
-                break
-        if hasattr(trainer.backend, "drop_dataset"):
-            trainer.backend.drop_dataset()
+        try:
+            for epoch in range(int(epochs)):
+                for cb in cbs:
+                    lr = cb.on_epoch_begin(epoch, lr)
+                trainer = self._trainer(batch_size)       # a callback may have replaced the weights
+                h1 = trainer.fit(x, y_labels, batch_size, 1, shuffle, lambda _e, _lr, _v=lr: _v, seed=epoch, verbose=0,
+                                 keep_resident=True)
+                self._dirty = True
+                logs = {"loss": h1["loss"][0], "lr": lr}
+                if validation_data is not None:
+                    vx, vy = validation_data
+                    vl = labels_from_targets(vy)
+                    p = self.predict(vx)
+                    reg = sum(float(self.spec.weight_decay) * float(np.sum(np.square(self._weights[n].astype(np.float64))))
+                              for n in self._l2_names())
+                    logs["val_loss"] = balanced_bce(p, vl) + reg
+                    logs["val_accuracy"] = float(np.mean(np.argmax(p, axis=1) == vl))
+                    logs["val_auc"] = roc_auc(vl, p[:, 1])
+                for k, v in logs.items():
+                    hist.setdefault(k, []).append(v)
+                if verbose:
+                    print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4g" % kv for kv in logs.items()))
+                for cb in cbs:
+                    cb.on_epoch_end(epoch, logs)
+                if any(cb.stop_training for cb in cbs):
+                    break
+        finally:
+            # the device copy of the training set never outlives fit(), whatever ends it (a callback that raises,
+            # an interrupt): a later fit() must not mistake it for its own data
+            for holder in (trainer, getattr(self, "_dp", None)):
+                if holder is not None and hasattr(holder.backend, "drop_dataset"):
+                    holder.backend.drop_dataset()
         for cb in cbs:
             cb.on_train_end()
         return hist

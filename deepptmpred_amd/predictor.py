@@ -201,13 +201,34 @@ class PTMPredictor:
         return pd.DataFrame(rows, columns=["protein_id", "position", "residue", "probability", "prediction"])
 
 
+    # a scoring call of predict_ptm_sites_batch holds at most this many bytes of ESM tables / this many sites on the host
+    BATCH_TABLE_BYTES = 2 << 30
+    BATCH_SITES = 1 << 20
+
     def predict_ptm_sites_batch(self, proteins):
-        """The loop a proteome run makes around ``predict_ptm_sites`` (predict.py:584-612), as ONE scoring call.
-        ``proteins``: iterable of dicts with ``protein_id``, ``protein_sequence`` and optionally ``positions``,
-        ``pdb_path``, ``struct_features`` (same meaning as the arguments of ``predict_ptm_sites``).  Returns one
-        DataFrame with the reference's columns, proteins in input order."""
+        """The loop a proteome run makes around ``predict_ptm_sites`` (predict.py:584-612) as a few large scoring
+        calls instead of one per protein.  ``proteins``: iterable of dicts with ``protein_id``, ``protein_sequence``
+        and optionally ``positions``, ``pdb_path``, ``struct_features`` (same meaning as the arguments of
+        ``predict_ptm_sites``).  Proteins are gathered until their ESM tables reach ``BATCH_TABLE_BYTES`` (or their
+        sites ``BATCH_SITES``), scored in ONE native call and released, so the host never holds more than one such
+        group of tables however long the input is (20,000 proteins' float tables are ~50 GB).  Returns one DataFrame
+        with the reference's columns, proteins in input order."""
         import pandas as pd
-        jobs, meta = [], []
+        cols = ["protein_id", "position", "residue", "probability", "prediction"]
+        frames, jobs, meta = [], [], []
+        held_bytes = held_sites = 0
+
+        def flush():
+            nonlocal jobs, meta, held_bytes, held_sites
+            if not jobs:
+                return
+            probas = self.model.predict_proteins(jobs)
+            rows = [{"protein_id": pid, "position": pos, "residue": seq[pos - 1], "probability": pr,
+                     "prediction": 1 if pr >= 0.5 else 0}
+                    for (pid, seq, positions), proba in zip(meta, probas) for pos, pr in zip(positions, proba[:, 1])]
+            frames.append(pd.DataFrame(rows, columns=cols))
+            jobs, meta, held_bytes, held_sites = [], [], 0, 0
+
         for p in proteins:
             pid, seq = p["protein_id"], p["protein_sequence"]
             positions = p.get("positions")
@@ -221,12 +242,15 @@ class PTMPredictor:
                     loader = PTMPredictDataLoader(self.config, None, self.data_loader.sasa_backend, self.data_loader.device)
                     loader.init_pyrosetta(p["pdb_path"])
                 st = loader._generate_structural_features(positions)
-            jobs.append((seq, positions, st, self.data_loader.load_custom_esm(pid)))
+            table = self.data_loader.load_custom_esm(pid)
+            jobs.append((seq, positions, st, table))
             meta.append((pid, seq, positions))
-        probas = self.model.predict_proteins(jobs)
-        rows = [{"protein_id": pid, "position": pos, "residue": seq[pos - 1], "probability": pr, "prediction": 1 if pr >= 0.5 else 0}
-                for (pid, seq, positions), proba in zip(meta, probas) for pos, pr in zip(positions, proba[:, 1])]
-        return pd.DataFrame(rows, columns=["protein_id", "position", "residue", "probability", "prediction"])
+            held_bytes += 0 if table is None else int(np.asarray(table).nbytes)
+            held_sites += len(positions)
+            if held_bytes >= self.BATCH_TABLE_BYTES or held_sites >= self.BATCH_SITES:
+                flush()
+        flush()
+        return pd.concat(frames, ignore_index=True) if frames else pd.DataFrame([], columns=cols)
 
 
 def run_protein(ptm_type: str, project_root: str, pdb_path: str, model_path: Optional[str] = None, out_dir: Optional[str] = None):

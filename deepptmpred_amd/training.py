@@ -7,15 +7,23 @@ backward -> AdamW.  The arithmetic runs in libdptm.so (``dptm_trainer_*``); this
 is host logic only: batching, the learning-rate schedule of trainer.py:56-59, and the
 data-parallel exchange (one process per GPU):
 
-  1. all-reduce (sum) of ``[N, N_pos]`` so every replica weights its samples with the
-     GLOBAL batch counts the single-device loss definition uses (trainer.py:39-44);
-  2. local forward/backward (BatchNorm normalises with the replica's own batch statistics, or --
-     ``sync_batchnorm=True`` -- with the global batch's: 20 more small all-reduces per step);
+  1. every replica is handed the labels of the WHOLE batch, so the GLOBAL counts ``N`` and
+     ``N_pos`` that the single-device loss definition weights its samples with
+     (trainer.py:39-44) are computed locally: no collective, no host round trip;
+  2. local forward/backward on the replica's contiguous shard (BatchNorm normalises with the
+     replica's own batch statistics, or -- ``sync_batchnorm=True`` -- with the global batch's:
+     20 more small all-reduces per step);
   3. ONE all-reduce (sum) over the flat fp32 gradient buffer: every tensor's gradient in
      one bucket, with the batch mean/variance of every BatchNorm riding in the slots of
-     its (untrained) moving statistics;
+     its (untrained) moving statistics and the replica's loss share in the bucket's spare
+     float, so the loss needs no collective of its own;
   4. identical AdamW update on every replica; moving statistics move towards the
      replica-averaged batch statistics, so replicas stay bit-identical.
+
+``fit`` keeps the training set on the device of EVERY replica (5.3 KB per site; the reference's
+largest set, 59,707 phosphorylation sites, is 0.3 GB), gathers each step's shard there and reads
+the per-step losses once per epoch, so that with one replica or many nothing in a step waits
+for the GPU or crosses PCIe.
 """
 from __future__ import annotations
 
@@ -96,8 +104,12 @@ class NativeBackend:
             __cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False), "version": 2}
         return self.torch.as_tensor(_Ext(), device=self.device)
 
+    device_loss = True       # the loss can stay on the device and ride in the gradient all-reduce (allreduce_grads)
+
     def forward_backward(self, x: Sequence[np.ndarray], labels: np.ndarray, n_global: int, n_pos_global: int,
-                         seed: int, rates: DropoutRates, l2: float, l2_scale: float) -> float:
+                         seed: int, rates: DropoutRates, l2: float, l2_scale: float, read_loss: bool = True):
+        """Stages one local batch and enqueues its step; returns this replica's loss share, or ``None``
+        without waiting for the GPU when ``read_loss`` is false."""
         t = self.torch
         # fixed staging buffers: a batch always lands at the same device addresses
         n = len(labels)
@@ -114,7 +126,7 @@ class NativeBackend:
                               non_blocking=False)
             d[5][:n].copy_(t.from_numpy(np.ascontiguousarray(labels, dtype=np.int32)))
             loss = self.trainer.forward_backward(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
-                                                 d[4].data_ptr(), d[5].data_ptr(), len(labels), o, True,
+                                                 d[4].data_ptr(), d[5].data_ptr(), len(labels), o, bool(read_loss),
                                                  self.stream.cuda_stream)
         return loss
 
@@ -132,6 +144,7 @@ class NativeBackend:
             return True
         if n * (sum(self.spec.window_sizes) + 4 * (self.spec.struct_feature_dim + self.spec.esm_dim) + 4) > self.RESIDENT_LIMIT_BYTES:
             return False
+        self.stream.wait_stream(t.cuda.current_stream(self.device))
         with t.cuda.stream(self.stream):
             data = [t.from_numpy(np.ascontiguousarray(a, dtype=np.uint8)).to(self.device) for a in x[:3]]
             data += [t.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device) for a in x[3:5]]
@@ -161,7 +174,8 @@ class NativeBackend:
     def forward_backward_resident(self, idx_dev, n_global: int, n_pos_global: int, seed: int, rates: DropoutRates,
                                   l2: float, l2_scale: float, loss_out) -> None:
         """One step on the rows ``idx_dev`` (device int64 tensor) of the resident data set; the step's loss is copied
-        to the one-element device tensor ``loss_out``.  Nothing here waits for the GPU."""
+        to the one-element device tensor ``loss_out`` (``None``: the caller takes it from ``allreduce_grads``).
+        Nothing here waits for the GPU."""
         t = self.torch
         d = self._staging()
         n = int(idx_dev.numel())
@@ -175,7 +189,8 @@ class NativeBackend:
                 t.index_select(a, 0, idx_dev, out=buf[:n])
             self.trainer.forward_backward(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
                                           d[4].data_ptr(), d[5].data_ptr(), n, o, False, self.stream.cuda_stream)
-            loss_out.copy_(self._loss_view, non_blocking=True)
+            if loss_out is not None:
+                loss_out.copy_(self._loss_view, non_blocking=True)
 
     def enable_sync_batchnorm(self, group=None) -> None:
         """Every BatchNorm then normalises with the statistics of the GLOBAL batch: its column sums are
@@ -205,17 +220,32 @@ class NativeBackend:
     def disable_sync_batchnorm(self) -> None:
         self.trainer.set_allreduce(None)
 
-    def allreduce_grads(self, group=None) -> None:
+    def allreduce_grads(self, group=None, loss_out=None) -> None:
         """ONE all-reduce (sum) of the flat gradient buffer, on the backend's stream (RCCL); host backends
-        (gloo: CPU tests, one-GPU rehearsals) go through host memory."""
+        (gloo: CPU tests, one-GPU rehearsals) go through host memory.  With ``loss_out`` (a one-element device
+        tensor) the replica's loss share rides in the bucket's spare float and the summed loss is copied there."""
         import torch.distributed as dist
         with self.torch.cuda.stream(self.stream):
+            slot = self.trainer.stage_loss(self.stream.cuda_stream) if loss_out is not None else -1
             if dist.get_backend(group) == "nccl":
                 dist.all_reduce(self._grad_view, op=dist.ReduceOp.SUM, group=group)
             else:
                 h = self._grad_view.cpu()                  # waits for the gradients on this stream
                 dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
                 self._grad_view.copy_(h)
+            if loss_out is not None:
+                loss_out.copy_(self._grad_view[slot:slot + 1], non_blocking=True)
+
+    def new_loss_buffer(self, n: int = 1):
+        """``n`` zeroed floats on the device, allocated in the order of the backend's stream."""
+        self.stream.wait_stream(self.torch.cuda.current_stream(self.device))
+        with self.torch.cuda.stream(self.stream):
+            return self.torch.zeros(n, dtype=self.torch.float32, device=self.device)
+
+    def read_floats(self, dev_tensor) -> np.ndarray:
+        """Host copy of a device tensor written on the backend's stream (waits for that stream)."""
+        with self.torch.cuda.stream(self.stream):
+            return dev_tensor.cpu().numpy()
 
     def apply(self, lr: float, weight_decay: float, stat_scale: float = 1.0) -> None:
         self.trainer.apply(lr, weight_decay, 1.0, stat_scale, self.stream.cuda_stream)
@@ -249,7 +279,9 @@ class DataParallelTrainer:
         return None, 0, 1
 
     def train_on_batch(self, x: Sequence[np.ndarray], y, lr: Optional[float] = None, seed: Optional[int] = None) -> float:
-        import torch
+        """One step on the global batch ``(x, y)``: every rank passes the same arrays, works on its shard and
+        returns the loss of the whole batch.  The only collective is the gradient all-reduce; the only wait for
+        the GPU is the read of the loss at the end."""
         dist, rank, world = self._dist()
         labels = labels_from_targets(y)
         n = len(labels)
@@ -260,21 +292,28 @@ class DataParallelTrainer:
             raise ValueError("every replica needs at least one sample of the batch")
         local_x = [np.asarray(a)[lo:hi] for a in x]
         local_y = labels[lo:hi]
-        counts = torch.tensor([float(hi - lo), float(local_y.sum())], dtype=torch.float64)
-        if dist is not None:
-            cdev = counts.cuda() if dist.get_backend(self.group) == "nccl" else counts
-            dist.all_reduce(cdev, op=dist.ReduceOp.SUM, group=self.group)
-            counts = cdev.cpu()
-        n_global, n_pos = int(round(counts[0].item())), int(round(counts[1].item()))
+        # N and N_pos of trainer.py:39-40 over the whole batch: every rank holds all labels
+        n_global, n_pos = n, int(labels.sum())
         step_seed = (self.steps if seed is None else seed) * 1000003 + rank
+        step_lr = self.optimizer.learning_rate if lr is None else lr
+        if dist is not None and getattr(self.backend, "device_loss", False):
+            self.backend.forward_backward(local_x, local_y, n_global, n_pos, step_seed, self.rates, self.l2, 1.0 / world,
+                                          read_loss=False)
+            if getattr(self, "_loss_dev", None) is None:
+                self._loss_dev = self.backend.new_loss_buffer(1)
+            self.backend.allreduce_grads(self.group, loss_out=self._loss_dev)
+            self.backend.apply(step_lr, self.optimizer.weight_decay, 1.0 / world)
+            self.steps += 1
+            return float(self.backend.read_floats(self._loss_dev)[0])
         loss = self.backend.forward_backward(local_x, local_y, n_global, n_pos, step_seed, self.rates, self.l2, 1.0 / world)
-        if dist is not None:
+        if dist is not None:       # a backend that hands its loss share to the host: one more small host all-reduce
+            import torch
             self.backend.allreduce_grads(self.group)
             lt = torch.tensor([loss], dtype=torch.float64)
             ldev = lt.cuda() if dist.get_backend(self.group) == "nccl" else lt
             dist.all_reduce(ldev, op=dist.ReduceOp.SUM, group=self.group)
             loss = float(ldev.cpu().item())
-        self.backend.apply(self.optimizer.learning_rate if lr is None else lr, self.optimizer.weight_decay, 1.0 / world)
+        self.backend.apply(step_lr, self.optimizer.weight_decay, 1.0 / world)
         self.steps += 1
         return loss
 
@@ -282,44 +321,56 @@ class DataParallelTrainer:
             lr_scheduler: Optional[Callable[[int, float], float]] = None, seed: int = 0, verbose: int = 0,
             keep_resident: bool = False) -> Dict[str, List[float]]:
         """``model.fit`` loop (trainer.py:332-339) without the reference's callbacks other
-        than the learning-rate schedule."""
+        than the learning-rate schedule.  ``batch_size`` is the GLOBAL batch; with several replicas every rank
+        calls this with the same arrays and seed, and takes its contiguous shard of every batch."""
         labels = y if isinstance(y, np.ndarray) and y.ndim == 1 and y.dtype == np.int32 else labels_from_targets(y)
         n = len(labels)
         lr = self.optimizer.learning_rate
         hist: Dict[str, List[float]] = {"loss": [], "lr": []}
         rng = np.random.default_rng(seed)
-        # one process: the data set goes to the device once, batches are gathered there, and the per-step losses are
-        # read once per epoch; same batches, seeds and arithmetic as the train_on_batch loop below
-        resident = self._dist()[2] == 1 and hasattr(self.backend, "set_dataset") and self.backend.set_dataset(x, labels)
-        for ep in range(epochs):
-            if lr_scheduler is not None:
-                lr = float(lr_scheduler(ep, lr))
-            order = rng.permutation(n) if shuffle else np.arange(n)
-            if resident:
-                torch = self.backend.torch
-                order_dev = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int64)).to(self.backend.device)
-                starts = list(range(0, n, batch_size))
-                losses_dev = torch.zeros(len(starts), dtype=torch.float32, device=self.backend.device)
-                for k, s in enumerate(starts):
-                    idx = order[s:s + batch_size]
-                    self.backend.forward_backward_resident(order_dev[s:s + len(idx)], len(idx), int(labels[idx].sum()),
-                                                           self.steps * 1000003, self.rates, self.l2, 1.0, losses_dev[k:k + 1])
-                    self.backend.apply(lr, self.optimizer.weight_decay, 1.0)
-                    self.steps += 1
-                with torch.cuda.stream(self.backend.stream):
-                    hist["loss"].append(float(losses_dev.double().mean().cpu()))
+        dist, rank, world = self._dist()
+        # the data set goes to the device once (every replica holds all of it: a shuffled batch may draw any row), the
+        # shards of a batch are gathered there, and the per-step losses are read once per epoch; same batches, seeds
+        # and arithmetic as the train_on_batch loop below
+        resident = hasattr(self.backend, "set_dataset") and self.backend.set_dataset(x, labels)
+        try:
+            for ep in range(epochs):
+                if lr_scheduler is not None:
+                    lr = float(lr_scheduler(ep, lr))
+                order = rng.permutation(n) if shuffle else np.arange(n)
+                if resident:
+                    torch = self.backend.torch
+                    starts = list(range(0, n, batch_size))
+                    losses_dev = self.backend.new_loss_buffer(len(starts))
+                    with torch.cuda.stream(self.backend.stream):
+                        order_dev = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int64)).to(self.backend.device)
+                    for k, s in enumerate(starts):
+                        idx = order[s:s + batch_size]
+                        lo, hi = shard_range(len(idx), rank, world)
+                        if hi - lo < 1:
+                            raise ValueError("every replica needs at least one sample of every batch")
+                        own = losses_dev[k:k + 1]
+                        self.backend.forward_backward_resident(order_dev[s + lo:s + hi], len(idx), int(labels[idx].sum()),
+                                                               self.steps * 1000003 + rank, self.rates, self.l2, 1.0 / world,
+                                                               own if world == 1 else None)
+                        if world > 1:
+                            self.backend.allreduce_grads(self.group, loss_out=own)
+                        self.backend.apply(lr, self.optimizer.weight_decay, 1.0 / world)
+                        self.steps += 1
+                    hist["loss"].append(float(self.backend.read_floats(losses_dev).astype(np.float64).mean()))
+                else:
+                    losses = []
+                    for s in range(0, n, batch_size):
+                        idx = order[s:s + batch_size]
+                        losses.append(self.train_on_batch([np.asarray(a)[idx] for a in x], labels[idx], lr))
+                    hist["loss"].append(float(np.mean(losses)))
                 hist["lr"].append(lr)
                 if verbose:
                     print(f"epoch {ep + 1}/{epochs} - loss {hist['loss'][-1]:.4f} - lr {lr:.2e}")
-                continue
-            losses = []
-            for s in range(0, n, batch_size):
-                idx = order[s:s + batch_size]
-                losses.append(self.train_on_batch([np.asarray(a)[idx] for a in x], labels[idx], lr))
-            hist["loss"].append(float(np.mean(losses)))
-            hist["lr"].append(lr)
-            if verbose:
-                print(f"epoch {ep + 1}/{epochs} - loss {hist['loss'][-1]:.4f} - lr {lr:.2e}")
+        except BaseException:
+            if resident:                        # never leave a device copy behind that a later call could mistake for its data
+                self.backend.drop_dataset()
+            raise
         if resident and not keep_resident:      # (keep_resident: the caller's next fit call passes the same arrays)
             self.backend.drop_dataset()
         return hist

@@ -162,7 +162,13 @@ int dptm_score_proteins_device(dptm_handle* h, const uint8_t* codes, const int64
  * DEVICE pointers, validated input.  Writes tok21/tok33/tok51 uint8 [n][W] and esm_row int32 [n]
  * (row of the concatenated tables, or -1 for a zero row).  One launch covers all n sites.  The arrays may
  * start at any byte; the kernel is at its fastest when codes starts on a 4-byte boundary (residues are then
- * fetched as 32-bit words) and the three outputs on 16-byte boundaries (16-byte stores). */
+ * fetched as 32-bit words) and the three outputs on 16-byte boundaries (16-byte stores).
+ * READ EXTENT of `codes` in every device form (this call, dptm_assemble_device, dptm_score_protein_device,
+ * dptm_score_proteins_device): when codes starts on a 4-byte boundary the kernel fetches whole 32-bit words, so
+ * the bytes up to the next 4-byte boundary behind the last residue are READ (never used: they are replaced by the
+ * padding code).  The array must be readable that far -- any hipMalloc'd buffer is; a sub-range that ends inside
+ * another allocation's last word is too; a sub-range that ends exactly at the end of a mapping whose size is not a
+ * multiple of 4 is not, and must be passed from an address that is not 4-byte aligned (byte path) or padded. */
 int dptm_assemble_proteins_device(dptm_handle* h, const uint8_t* codes, const int64_t* seq_offsets,
                                   const int64_t* esm_offsets, const int32_t* positions,
                                   const int32_t* site_protein, int64_t n, uint8_t* tok21, uint8_t* tok33,
@@ -260,7 +266,8 @@ int dptm_trainer_forward_backward(dptm_trainer* t, const uint8_t* tok21, const u
                                   float* loss_out, void* stream);
 
 /* Device address and length (floats) of the flat gradient buffer: one contiguous fp32
- * array holding every tensor's gradient (256-byte aligned slots, padding stays zero; the
+ * array holding every tensor's gradient (256-byte aligned slots, padding stays zero but for the last float, see
+ * dptm_trainer_stage_loss; the
  * slots of the BatchNorm moving statistics hold the batch statistics), the single bucket
  * a data-parallel job all-reduces per step. */
 int dptm_trainer_grad_buffer(dptm_trainer* t, float** dev_ptr, int64_t* count);
@@ -301,6 +308,19 @@ int dptm_trainer_set_optimizer_state(dptm_trainer* t, const float* m_host, const
  * step and reads the copies once per epoch need not wait for the GPU at every step, as Keras' model.fit does not
  * (pred/train_PTM/trainer.py:332-339: the per-batch losses only surface as the epoch's mean). */
 int dptm_trainer_loss_buffer(dptm_trainer* t, float** dev_ptr);
+
+/* Data-parallel jobs: copies the step's loss (dptm_trainer_loss_buffer) into a float of the gradient buffer that no
+ * parameter uses -- the last float of the buffer, padding behind the head bias -- in stream order, and returns that
+ * float's index in `slot`.  The ONE all-reduce of the gradient bucket then also sums the replicas' loss shares, and a
+ * training loop needs no collective or host round trip of its own for the loss.  The matching float of the weights is
+ * padding too; dptm_trainer_apply leaves a moving average of the staged value there, which nothing reads.  No
+ * counterpart in the reference (one device: trainer.py:332). */
+int dptm_trainer_stage_loss(dptm_trainer* t, int64_t* slot, void* stream);
+
+/* How many of the step's four lanes (main stream + three side streams) the trainer's queue probe found on hardware
+ * queues of their own when it was created: 4 = every lane runs concurrently; fewer = lanes beyond that number share
+ * a queue with an earlier lane and serialise behind it (a performance diagnostic, results do not depend on it). */
+int dptm_trainer_lanes(dptm_trainer* t, int32_t* independent_out);
 
 /* The stream the step's main lane runs on (a hipStream_t the trainer owns; it dies with the trainer).  The step
  * always runs on the trainer's own streams, one per hardware queue of the process; a call made on another stream

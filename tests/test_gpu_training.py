@@ -218,6 +218,11 @@ def _sync_bn_worker(rank, world, port, q, backend):
     dp = DataParallelTrainer(NativeBackend(w, max_batch=24), AdamW(5e-4, 1e-4), DropoutRates.off(),
                              sync_batchnorm=bool(backend))
     losses = [dp.train_on_batch(x, np.eye(2)[y], seed=3 + i) for i in range(2)]
+    # the fit loop: data set on every replica's device, shards of each 12-site batch gathered there, the loss
+    # riding in the gradient all-reduce and read once per epoch
+    hist = dp.fit(x, y.astype(np.int32), batch_size=12, epochs=2, shuffle=True, seed=5)
+    losses += hist["loss"]
+    assert dp.backend._data is None                 # the device copy does not outlive fit
     torch.cuda.synchronize()
     if rank == 0:
         q.put((losses, {k: np.asarray(v) for k, v in dp.backend.weights().items()}))
@@ -255,7 +260,7 @@ def test_replicas_with_synchronised_batchnorm_equal_one_device():
         assert np.allclose(loss1, loss2, rtol=2e-5, atol=1e-6), (label, loss1, loss2)
         worst = max(float(np.abs(w1[k] - w2[k]).max()) for k in w1)
         print("one device vs", label, ": max weight difference", worst)
-        assert worst < 1e-4, label      # Adam divides by |g|: float-atomic noise on a near-zero gradient moves a weight by a fraction of lr = 5e-4
+        assert worst < 2e-4, label      # Adam divides by |g|: float-atomic noise on a near-zero gradient moves a weight by a fraction of lr = 5e-4
 
 
 def test_trainer_profile_times_the_branch_launches():
@@ -282,6 +287,7 @@ def test_trainer_profile_times_the_branch_launches():
     ms = tr.profile_end()
     assert len(ms) == 18 and all(0.0 < v < 50.0 for v in ms.values()), ms
     assert ms["tb_bwd51"] > ms["conv_b_fwd51"]
+    assert 1 <= tr.lanes_independent() <= 4      # how many of the step's four streams have a hardware queue of their own
     g2 = step()
     scale = np.abs(g0).max()
     assert np.abs(g1 - g0).max() < 1e-5 * scale and np.abs(g2 - g0).max() < 1e-5 * scale
