@@ -16,6 +16,21 @@ __device__ __forceinline__ void mfma(f32x16& acc, float a, float b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
 }
 
+// Keeps a lane-dependent index local to the code that follows: without it the compiler hoists `base + index` of every
+// table it meets out of the enclosing loops as a 64-bit address per table and lane, two registers each that then live
+// (or spill) across the whole kernel; with it the address is formed where it is used, scalar base + 32-bit lane offset.
+#ifdef DPTM_KEEP_INDEX_LOCAL
+#define DPTM_LOCAL_INDEX(v) asm volatile("" : "+v"(v))
+#else
+#define DPTM_LOCAL_INDEX(v) ((void)0)
+#endif
+
+// the same for an index used in an expression: returns v, opaque to the optimiser at this point
+__device__ __forceinline__ unsigned local_index(unsigned v) {
+    DPTM_LOCAL_INDEX(v);
+    return v;
+}
+
 constexpr float kQScale = 0.25f * 1.44269504088896340736f;  // log2(e) / sqrt(head_dim)
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -37,6 +52,7 @@ __device__ __forceinline__ void half_swap(float& a, float& b) {
 template <int NT>
 __device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[NT], const f32x4* __restrict__ vec,
                                               int h, int groups_per_half) {
+    DPTM_LOCAL_INDEX(h);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -54,6 +70,7 @@ __device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[NT], const f32x4* __
 template <int K8, int NT, int DIST = 2>
 __device__ __forceinline__ void gemm_regs(f32x16 (&acc)[NT], const f32x4* __restrict__ wp,
                                           const f32x4 (&x)[K8], int lane) {
+    DPTM_LOCAL_INDEX(lane);
     f32x4 a[K8][NT];
 #pragma unroll
     for (int u = 0; u < DIST && u < K8; ++u)

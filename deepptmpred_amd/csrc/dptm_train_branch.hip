@@ -22,6 +22,7 @@
 
 #include <cstdlib>
 
+#define DPTM_KEEP_INDEX_LOCAL 1
 #include "dptm_attend.h"
 #include "dptm_layout.h"
 #include "dptm_mfma.h"
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
     float* xreg = bufB + img;
     float* vacc = xreg + kXreg;                     // [kTbVecs][64] column sums of this workgroup
     float* bnv = vacc + kTbVecs * 64;               // [scale | shift] of the second BatchNorm
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31;
     const unsigned seed = p.step[kStepSeed];
     const int S = p.S;
@@ -469,8 +470,13 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
         const int rows_valid = sites_here * W;
         const bool row_ok = row < rows_valid;
         const int64_t grow = site0 * W + row;
-        const int64_t ct = ((tile * NW + wave) * 8) * 64 + lane;
-        const int64_t cl = (tile * NW + wave) * 64 + lane;
+        // Addresses of the kept arrays: the tile and the wavefront are the same for every lane, so (tile, wavefront) goes
+        // into a scalar base per array and the lane adds one 32-bit offset that all arrays share -- a 64-bit address per
+        // array and lane would cost two registers each, and there are two dozen arrays.
+        const int64_t tw = (int64_t)__builtin_amdgcn_readfirstlane((int)tile) * NW + wave;     // chain-tiled slab of this wavefront
+        unsigned ln = (unsigned)lane;
+#define AT4(arr, u) ((arr) + tw * 512 + (u) * 64)[local_index(ln)]
+#define AT1(arr) ((arr) + tw * 64)[local_index(ln)]
         f32x4 dy[8];   // gradient w.r.t. the output of the block in hand
         TB_SYNC();   // the previous tile's last exchange through xreg has been read
         // ---- attention pooling backward: dx_t = alpha_t dout + dz_t w, dz_t = alpha_t (dalpha_t - sum alpha dalpha)(1 - a_t^2)
@@ -479,9 +485,9 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
             const f32x4* pv = p.P + kOffPoolV;
             f32x4 x[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = keep_load(&p.sv[1].xh2[CTL(ct) + u * 64]);
+            for (int u = 0; u < 8; ++u) x[u] = keep_load(&AT4(p.sv[1].xh2, u));
             ln_affine(x, tv1 + kVLn2G * kVec64, tv1 + kVLn2B * kVec64, h, x);
-            const f32x2 pa = p.pool[cl];
+            const f32x2 pa = AT1(p.pool);
             const float* dsite = p.dout + (site0 + row / W) * p.ldd + p.col_off;
             f32x4 ds[8];
             float dal = 0.f;
@@ -525,13 +531,13 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
             const TbSave& sv = p.sv[blk];
             float* pu = part + (size_t)blk * 12 * 4096;
             float* va = vacc + blk * kSlotsPerBlock * 64 + lane;
-            const f32x2 iv = sv.inv[cl];
+            const f32x2 iv = AT1(sv.inv);
             // ---- LayerNorm 2 backward: dy -> dsum = d(h + f2)
             f32x4 dsum[8];
             {
                 f32x4 xh[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) xh[u] = keep_load(&sv.xh2[CTL(ct) + u * 64]);
+                for (int u = 0; u < 8; ++u) xh[u] = keep_load(&AT4(sv.xh2, u));
                 ln_backward(dy, xh, iv[1], tv + kVLn2G * kVec64, h, dsum, lane_a, lane_b);
                 wave_fence();
                 atomicAdd(va + kSG2 * 64, colsum32_t(bufA, row0, lane));
@@ -547,7 +553,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
             {
                 f32x4 xh[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) xh[u] = keep_load(&sv.xh1[CTL(ct) + u * 64]);
+                for (int u = 0; u < 8; ++u) xh[u] = keep_load(&AT4(sv.xh1, u));
                 ln_affine(xh, tv + kVLn1G * kVec64, tv + kVLn1B * kVec64, h, hx);
             }
             // ---- feed-forward layers backward; the hidden layer is rebuilt in four 64-wide chunks
@@ -608,7 +614,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
                 f32x4 dh[8], xh[8];
                 acc_to_x<2>(acc_dh, dh);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) xh[u] = keep_load(&sv.xh1[CTL(ct) + u * 64]);
+                for (int u = 0; u < 8; ++u) xh[u] = keep_load(&AT4(sv.xh1, u));
                 ln_backward(dh, xh, iv[0], tv + kVLn1G * kVec64, h, dsum, lane_a, lane_b);
                 wave_fence();
                 atomicAdd(va + kSG1 * 64, colsum32_t(bufA, row0, lane));
@@ -624,7 +630,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     dao[u] = dsum[u];
-                    o[u] = keep_load(&sv.o[CTL(ct) + u * 64]);
+                    o[u] = keep_load(&AT4(sv.o, u));
                 }
                 dropout_chain(dao, grow, h, seed, p.stream_base + 2 * blk, p.thr, p.scale);
                 chain_store_t(lane_a, o);
@@ -650,7 +656,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
                 D[1] = h ? d4[3] : d4[1];
             }
             PH_MARK(5)   // output projection backward
-            const f32x4 st = sv.stat[cl];
+            const f32x4 st = AT1(sv.stat);
             f32x16 acc_dx[2];   // d(x) = dsum + dq Wq^T + dk Wk^T + dv Wv^T, summed as the terms appear
             // ---- attention backward, lane = query row: dq
             {
@@ -658,14 +664,14 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
                 {
                     f32x4 t[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = keep_load(&sv.k[CTL(ct) + u * 64]);
+                    for (int u = 0; u < 8; ++u) t[u] = keep_load(&AT4(sv.k, u));
                     chain_store(mine_a, h, t);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = keep_load(&sv.v[CTL(ct) + u * 64]);
+                    for (int u = 0; u < 8; ++u) t[u] = keep_load(&AT4(sv.v, u));
                     chain_store(mine_b, h, t);
                     float qs[2][16], doh[2][16], gh[2][16];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = keep_load(&sv.q[CTL(ct) + u * 64]);
+                    for (int u = 0; u < 8; ++u) t[u] = keep_load(&AT4(sv.q, u));
                     x_to_heads(t, qs, kQScale);
                     x_to_heads(dO, doh, 1.0f);
                     TB_SYNC();   // K and V of the tile are in LDS
@@ -682,11 +688,11 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
                 {
                     f32x4 xin[8];
                     if (blk == 0) {
-                        x1_from_conv(p.cs, CTL(ct), bnv, h, row_ok, xin);
+                        x1_from_conv(p.cs.a2 + tw * 512, p.cs.s + tw * 512, local_index(ln), bnv, h, row_ok, xin);
                     } else {
                         const f32x4* tv0 = p.P + kOffTb + kTbVec;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) xin[u] = keep_load(&p.sv[0].xh2[CTL(ct) + u * 64]);
+                        for (int u = 0; u < 8; ++u) xin[u] = keep_load(&AT4(p.sv[0].xh2, u));
                         ln_affine(xin, tv0 + kVLn2G * kVec64, tv0 + kVLn2B * kVec64, h, xin);
                     }
                     chain_store_t(lane_a, xin);
@@ -706,7 +712,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
                 {
                     f32x4 t[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = keep_load(&sv.q[CTL(ct) + u * 64]) * kQScale;
+                    for (int u = 0; u < 8; ++u) t[u] = keep_load(&AT4(sv.q, u)) * kQScale;
                     chain_store(mine_a, h, t);
                     chain_store(mine_b, h, dO);
 #pragma unroll
@@ -717,10 +723,10 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
                     }
                     float kh[2][16], vh[2][16], gk[2][16], gv[2][16];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = keep_load(&sv.k[CTL(ct) + u * 64]);
+                    for (int u = 0; u < 8; ++u) t[u] = keep_load(&AT4(sv.k, u));
                     x_to_heads(t, kh, 1.0f);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = keep_load(&sv.v[CTL(ct) + u * 64]);
+                    for (int u = 0; u < 8; ++u) t[u] = keep_load(&AT4(sv.v, u));
                     x_to_heads(t, vh, 1.0f);
                     TB_SYNC();   // scaled Q, dO and the statistics of the tile are in LDS
 #pragma unroll
@@ -738,11 +744,11 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
                 {
                     f32x4 xin[8];
                     if (blk == 0) {
-                        x1_from_conv(p.cs, CTL(ct), bnv, h, row_ok, xin);
+                        x1_from_conv(p.cs.a2 + tw * 512, p.cs.s + tw * 512, local_index(ln), bnv, h, row_ok, xin);
                     } else {
                         const f32x4* tv0 = p.P + kOffTb + kTbVec;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) xin[u] = keep_load(&p.sv[0].xh2[CTL(ct) + u * 64]);
+                        for (int u = 0; u < 8; ++u) xin[u] = keep_load(&AT4(p.sv[0].xh2, u));
                         ln_affine(xin, tv0 + kVLn2G * kVec64, tv0 + kVLn2B * kVec64, h, xin);
                     }
                     chain_store_t(lane_a, xin);
@@ -768,8 +774,8 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
             f32x4 t[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                p.dx1[ct + u * 64] = dy[u];
-                const f32x4 a = p.cs.a2[CTL(ct) + u * 64];
+                AT4(p.dx1, u) = dy[u];
+                const f32x4 a = AT4(p.cs.a2, u);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) t[u][e] = dy[u][e] * swishf(a[e]);
             }
@@ -794,6 +800,8 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
             part[kTbUnits * 4096 + i] = vacc[i];
     }
     PH_FLUSH
+#undef AT4
+#undef AT1
 }
 
 // ------------------------------------------------------------------------------------ partial sums -> gradients

@@ -63,7 +63,10 @@ __device__ __forceinline__ float colsum32(const float* img_rows, int lane) {
 __device__ __forceinline__ void dropout_chain(f32x4 (&x)[8], int64_t r, int h, unsigned seed, unsigned stream, unsigned thr,
                                               float scale) {
     if (thr == 0u) return;
-    const unsigned base = (unsigned)(r * 64) + 4 * h;
+    unsigned base = (unsigned)(r * 64) + 4 * h;
+    // (kept local: the first mixing step of the hash depends on the element index and the seed only, and the compiler
+    // would otherwise keep all 32 of them per lane alive across the kernel for the next dropout site to reuse)
+    DPTM_LOCAL_INDEX(base);
 #pragma unroll
     for (int u = 0; u < 8; ++u)
 #pragma unroll
@@ -74,6 +77,7 @@ __device__ __forceinline__ void dropout_chain(f32x4 (&x)[8], int64_t r, int h, u
 // image has 32 feature groups per out tile, the chunk owns groups 8c .. 8c+7
 __device__ __forceinline__ void gemm_k256_chunk(f32x16 (&acc)[2], const f32x4* __restrict__ wp, int c, const f32x4 (&x)[8],
                                                 int lane) {
+    DPTM_LOCAL_INDEX(lane);
     f32x4 a[8][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -155,6 +159,7 @@ __device__ __forceinline__ float ln_normalise(f32x4 (&y)[8]) {
 // out = xhat * gamma + beta with packed vectors (float4 index h*8 + u)
 __device__ __forceinline__ void ln_affine(const f32x4 (&xh)[8], const f32x4* __restrict__ g, const f32x4* __restrict__ b, int h,
                                           f32x4 (&out)[8]) {
+    DPTM_LOCAL_INDEX(h);
 #pragma unroll
     for (int u = 0; u < 8; ++u) out[u] = xh[u] * g[h * 8 + u] + b[h * 8 + u];
 }
@@ -184,6 +189,7 @@ __device__ __forceinline__ float colsum32_t(const float* imgT, int row0, int lan
 // colsum32_t takes them.
 __device__ __forceinline__ void ln_backward(const f32x4 (&dy)[8], const f32x4 (&xh)[8], float inv, const f32x4* __restrict__ g,
                                             int h, f32x4 (&dsum)[8], float* lane_a, float* lane_b) {
+    DPTM_LOCAL_INDEX(h);
     float s1 = 0.f, s2 = 0.f;
     f32x4 t[8];
 #pragma unroll
@@ -362,6 +368,19 @@ __device__ __forceinline__ void x1_from_conv(const ConvSave& cs, int64_t ct, con
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const f32x4 a = cs.a2[ct + u * 64], sv = cs.s[ct + u * 64];
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(bnv + 8 * u + 4 * h);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(bnv + 64 + 8 * u + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x1[u][e] = row_ok ? fmaf(swishf(a[e]), sc[e], sh[e]) + sv[e] : 0.f;
+    }
+}
+
+// the same with the two arrays given as the wavefront's chain-tiled slab (scalar base) and the lane as a 32-bit offset
+__device__ __forceinline__ void x1_from_conv(const f32x4* a2w, const f32x4* sw, unsigned ln, const float* bnv, int h, bool row_ok,
+                                             f32x4 (&x1)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const f32x4 a = (a2w + u * 64)[ln], sv = (sw + u * 64)[ln];
         const f32x4 sc = *reinterpret_cast<const f32x4*>(bnv + 8 * u + 4 * h);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(bnv + 64 + 8 * u + 4 * h);
 #pragma unroll
