@@ -29,7 +29,7 @@ EXPORTS = (
     "dptm_score_proteins", "dptm_score_proteins_device", "dptm_assemble_proteins_device",
     "dptm_score_device_noalloc", "dptm_noalloc_max_sites",
     "dptm_profile_begin", "dptm_profile_end", "dptm_chunk_sites", "dptm_last_error",
-    "dptm_set_precision", "dptm_trainer_create", "dptm_trainer_destroy", "dptm_trainer_forward_backward",
+    "dptm_set_precision", "dptm_convert_rows", "dptm_trainer_create", "dptm_trainer_destroy", "dptm_trainer_forward_backward",
     "dptm_trainer_grad_buffer", "dptm_trainer_param_floats", "dptm_trainer_apply",
     "dptm_trainer_get_weights", "dptm_trainer_get_grads", "dptm_trainer_get_proba",
     "dptm_trainer_get_optimizer_state", "dptm_trainer_set_optimizer_state",
@@ -152,6 +152,8 @@ def load_library() -> C.CDLL:
     lib.dptm_profile_end.argtypes = [vp, C.c_void_p, C.c_void_p]
     lib.dptm_set_precision.restype = C.c_int
     lib.dptm_set_precision.argtypes = [vp, C.c_int]
+    lib.dptm_convert_rows.restype = C.c_int
+    lib.dptm_convert_rows.argtypes = [f32p, i64, C.c_int, vp]
     lib.dptm_chunk_sites.restype = C.c_int64
     lib.dptm_chunk_sites.argtypes = [vp]
     lib.dptm_last_error.restype = C.c_char_p
@@ -200,6 +202,16 @@ def load_library() -> C.CDLL:
     lib.dptm_sasa_last_error.argtypes = []
     _lib = lib
     return lib
+
+
+def convert_rows(a: np.ndarray, mode: str) -> np.ndarray:
+    """fp32 array -> uint16 array of the same shape holding the bfloat16 / float16 bit patterns the library's host
+    pipelines send over PCIe in the "bf16" / "f16" modes (round to nearest even)."""
+    lib = load_library()
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    out = np.empty(a.shape, dtype=np.uint16)
+    _check(lib, lib.dptm_convert_rows(_ptr(a), a.size, PRECISIONS[mode], _ptr(out)), "dptm_convert_rows")
+    return out
 
 
 def _check(lib, rc: int, what: str) -> None:

@@ -7,12 +7,17 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
 #include <string>
 #include <thread>
 #include <vector>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "../../include/dptm.h"
 #include "dptm_kernels.h"
@@ -399,10 +404,11 @@ struct Prof {
 
 int run_dense(dptm_handle* h, const DenseLayer& L, int epi, const float* x, int64_t ldx,
               const int32_t* row_index, int64_t m, float* out, int64_t ldo, int col_off,
-              hipStream_t st, int cls) {
+              hipStream_t st, int cls, bool x_half = false) {
     DenseArgs a;
     a.x = x;
     a.ldx = ldx;
+    a.x_half = x_half ? 1 : 0;
     a.row_index = row_index;
     a.m = m;
     a.k = L.k;
@@ -415,7 +421,9 @@ int run_dense(dptm_handle* h, const DenseLayer& L, int epi, const float* x, int6
     a.ldo = ldo;
     a.col_off = col_off;
     Prof p(h, st, cls);
-    if (h->precision != kModeF32 && L.d_w_half[0] && epi != kEpiHead && m > kDenseSmallRows) {
+    if (x_half && (h->precision == kModeF32 || h->precision == kModeF16X3 || !L.d_w_half[0]))
+        return fail(DPTM_EINVAL, "16-bit input rows need the bf16 or f16 mode");
+    if (h->precision != kModeF32 && L.d_w_half[0] && epi != kEpiHead && (m > kDenseSmallRows || x_half)) {
         HIP_TRY(launch_dense_h(h->precision, a, epi, L.d_w_half[h->precision == kModeBF16 ? 0 : 1], L.d_w_half[2], st));
     } else {
         HIP_TRY(launch_dense(a, epi, st));   // fp32: the 8-feature structure layer, the 2-class head, small calls
@@ -424,8 +432,9 @@ int run_dense(dptm_handle* h, const DenseLayer& L, int epi, const float* x, int6
 }
 
 // One chunk (m <= kChunkSites) of the forward pass, everything device-resident.
+// esm_half: the ESM rows hold the mode's bfloat16 / float16 values (what the host pipelines send in those modes)
 int score_chunk(dptm_handle* h, const Workspace& ws, const uint8_t* const tok[3], const float* strct, const float* esm,
-                int64_t esm_ld, const int32_t* esm_row, int64_t m, float* out, hipStream_t st) {
+                int64_t esm_ld, const int32_t* esm_row, int64_t m, float* out, hipStream_t st, bool esm_half = false) {
     // A small call cannot fill the chip with any one kernel, so its three sequence branches run on side
     // streams next to the structure / ESM layers; a large call keeps everything on one stream.
     const bool fan_out = m <= kDenseSmallRows && !h->prof_armed && !h->plain;
@@ -458,7 +467,7 @@ int score_chunk(dptm_handle* h, const Workspace& ws, const uint8_t* const tok[3]
                         3 * kD, st, DPTM_PROF_STRUCT)))
         return rc;
     if ((rc = run_dense(h, h->esm1, kEpiSwishAffine, esm, esm_ld, esm_row, m, ws.h1, kEsm1, 0, st,
-                        DPTM_PROF_ESM1)))
+                        DPTM_PROF_ESM1, esm_half)))
         return rc;
     if ((rc = run_dense(h, h->esm2, kEpiSwish, ws.h1, kEsm1, nullptr, m, ws.concat, kConcat,
                         3 * kD + kStructUnits, st, DPTM_PROF_ESM2)))
@@ -492,31 +501,128 @@ constexpr size_t kPinTok33 = kPinTok21 + (size_t)kChunkSites * 21;
 constexpr size_t kPinTok51 = kPinTok33 + (size_t)kChunkSites * 33;
 constexpr size_t kPinInBytes = kPinTok51 + (size_t)kChunkSites * 51;
 
-// memcpy split over a few threads: one core moves ~10 GB/s, PCIe takes 50+
-void parallel_copy(void* dst, const void* src, size_t bytes) {
-    constexpr size_t kMinPerThread = 8u << 20;
-    unsigned hw = std::thread::hardware_concurrency();
-    size_t nt = std::min<size_t>(std::min<unsigned>(hw ? hw : 1u, 6u), bytes / kMinPerThread);
+// threads of the host-side gather / conversion: one core moves ~10 GB/s, PCIe takes 50+ (DPTM_HOST_THREADS overrides)
+unsigned host_threads() {
+    static const unsigned v = [] {
+        if (const char* e = std::getenv("DPTM_HOST_THREADS")) {
+            const long x = std::atol(e);
+            if (x >= 1 && x <= 256) return (unsigned)x;
+        }
+        const unsigned hw = std::thread::hardware_concurrency();
+        return std::min<unsigned>(hw ? hw : 1u, 12u);
+    }();
+    return v;
+}
+
+// work(a, b) over [0, n) in slices of at least `grain` on a few threads; the first slice runs on the caller's thread
+template <typename F>
+void parallel_slices(size_t n, size_t grain, F work) {
+    size_t nt = std::min<size_t>(host_threads(), n / std::max<size_t>(grain, 1));
     if (nt <= 1) {
-        std::memcpy(dst, src, bytes);
+        work((size_t)0, n);
         return;
     }
-    const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
+    const size_t per = (n + nt - 1) / nt;
     std::vector<std::thread> pool;
     pool.reserve(nt);
-    for (size_t t = 1; t < nt; ++t) {
-        const size_t off = t * per;
-        if (off >= bytes) break;
-        const size_t len = std::min(per, bytes - off);
+    size_t done = std::min(per, n);
+    for (size_t t = 1; t < nt && done < n; ++t) {
+        const size_t a = done, b = std::min(n, a + per);
         try {
-            pool.emplace_back([=] { std::memcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, len); });
-        } catch (...) {   // no more threads to be had: this slice and the rest are copied here
-            std::memcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, bytes - off);
+            pool.emplace_back(work, a, b);
+        } catch (...) {   // no more threads to be had: the rest runs here
+            work(a, n);
+            done = n;
             break;
         }
+        done = b;
     }
-    std::memcpy(dst, src, std::min(per, bytes));
+    work((size_t)0, std::min(per, n));
     for (auto& th : pool) th.join();
+}
+
+// memcpy split over a few threads
+void parallel_copy(void* dst, const void* src, size_t bytes) {
+    constexpr size_t kMinPerThread = 8u << 20;
+    parallel_slices(bytes >> 12, kMinPerThread >> 12, [=](size_t p0, size_t p1) {      // in 4 KiB pages
+        const size_t lo = p0 << 12, hi = p1 == (bytes >> 12) ? bytes : p1 << 12;
+        std::memcpy(static_cast<char*>(dst) + lo, static_cast<const char*>(src) + lo, hi - lo);
+    });
+    if ((bytes >> 12) == 0) std::memcpy(dst, src, bytes);
+}
+
+// ---- fp32 -> bfloat16 / float16 on the host, round to nearest even: the values the kernels' own conversions give, so a
+// row converted here and a row converted on the device score alike bit for bit.  In the one-operand half-precision
+// modes the host pipelines send the ESM rows in this form: half the bytes over PCIe.
+inline uint16_t bf16_rne(float f) {
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    if ((x & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((x >> 16) | 0x40u);     // NaN stays NaN (quiet)
+    x += 0x7fffu + ((x >> 16) & 1u);
+    return (uint16_t)(x >> 16);
+}
+inline uint16_t f16_rne(float f) {
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                        // NaN
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                       // rounds to infinity (>= 65520)
+    if (x < 0x38800000u) {                                                         // subnormal half or zero
+        if (x < 0x33000000u) return (uint16_t)sign;                                // below half of the smallest subnormal
+        const uint32_t e = x >> 23, m = (x & 0x7fffffu) | 0x800000u;
+        const uint32_t shift = 126u - e;                                           // 14 .. 24
+        uint32_t r = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (r & 1u))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = x - 0x38000000u;                                                  // rebias 127 -> 15
+    r += 0xfffu + ((r >> 13) & 1u);
+    return (uint16_t)(sign | (r >> 13));
+}
+void convert_rows_scalar(uint16_t* dst, const float* src, size_t n, int mode) {
+    if (mode == kModeBF16)
+        for (size_t i = 0; i < n; ++i) dst[i] = bf16_rne(src[i]);
+    else
+        for (size_t i = 0; i < n; ++i) dst[i] = f16_rne(src[i]);
+}
+#if defined(__x86_64__)
+__attribute__((target("avx2,f16c"))) void convert_rows_avx2(uint16_t* dst, const float* src, size_t n, int mode) {
+    size_t i = 0;
+    if (mode == kModeBF16) {
+        const __m256i bias = _mm256_set1_epi32(0x7fff), one = _mm256_set1_epi32(1), absm = _mm256_set1_epi32(0x7fffffff),
+                      inf = _mm256_set1_epi32(0x7f800000), quiet = _mm256_set1_epi32(0x40);
+        for (; i + 16 <= n; i += 16) {
+            __m256i r[2];
+            for (int k = 0; k < 2; ++k) {
+                const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 8 * k));
+                const __m256i rounded = _mm256_srli_epi32(_mm256_add_epi32(x, _mm256_add_epi32(bias, _mm256_and_si256(_mm256_srli_epi32(x, 16), one))), 16);
+                const __m256i is_nan = _mm256_cmpgt_epi32(_mm256_and_si256(x, absm), inf);
+                r[k] = _mm256_blendv_epi8(rounded, _mm256_or_si256(_mm256_srli_epi32(x, 16), quiet), is_nan);
+            }
+            const __m256i packed = _mm256_permute4x64_epi64(_mm256_packus_epi32(r[0], r[1]), 0xd8);
+            _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst + i), packed);
+        }
+    } else {
+        for (; i + 8 <= n; i += 8)
+            _mm_storeu_si128(reinterpret_cast<__m128i*>(dst + i),
+                             _mm256_cvtps_ph(_mm256_loadu_ps(src + i), _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
+    }
+    convert_rows_scalar(dst + i, src + i, n - i, mode);
+}
+#endif
+void convert_rows(uint16_t* dst, const float* src, size_t n, int mode) {
+#if defined(__x86_64__)
+    static const bool fast = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("f16c");
+    if (fast) return convert_rows_avx2(dst, src, n, mode);
+#endif
+    convert_rows_scalar(dst, src, n, mode);
+}
+
+// m rows of 1280 floats -> the mode's 16-bit values, on a few threads
+void parallel_convert(uint16_t* dst, const float* src, int64_t m, int mode) {
+    parallel_slices((size_t)m, 1024, [=](size_t a, size_t b) { convert_rows(dst + a * kEsm, src + a * kEsm, (b - a) * kEsm, mode); });
 }
 
 int ensure_pipeline(dptm_handle* h) {
@@ -582,43 +688,30 @@ struct DrainOnError {
 };
 
 // rows of the concatenated ESM tables that the sites [i0, i1) need, gathered into dst [i1-i0][1280]
-// (zero row when the protein has no table or the position lies beyond it: predict.py:493,498-500)
-void gather_esm_rows(float* dst, const float* tables, const int64_t* esm_off, const int32_t* positions,
-                     const int32_t* site_protein, int64_t i0, int64_t i1) {
-    auto work = [=](int64_t a, int64_t b) {
-        for (int64_t i = a; i < b; ++i) {
+// (zero row when the protein has no table or the position lies beyond it: predict.py:493,498-500);
+// half_mode != 0: dst receives the rows as that mode's 16-bit values (uint16 [i1-i0][1280])
+void gather_esm_rows(void* dst, const float* tables, const int64_t* esm_off, const int32_t* positions,
+                     const int32_t* site_protein, int64_t i0, int64_t i1, int half_mode = 0) {
+    parallel_slices((size_t)(i1 - i0), 2048, [=](size_t a, size_t b) {
+        for (int64_t i = i0 + (int64_t)a; i < i0 + (int64_t)b; ++i) {
             const int64_t p = site_protein[i], r = (int64_t)positions[i] - 1;
-            float* d = dst + (i - i0) * (int64_t)kEsm;
-            if (tables && r < esm_off[p + 1] - esm_off[p])
-                std::memcpy(d, tables + (esm_off[p] + r) * (int64_t)kEsm, kEsm * sizeof(float));
-            else
-                std::memset(d, 0, kEsm * sizeof(float));
+            const bool have = tables && r < esm_off[p + 1] - esm_off[p];
+            const float* srow = have ? tables + (esm_off[p] + r) * (int64_t)kEsm : nullptr;
+            if (half_mode) {
+                uint16_t* d = static_cast<uint16_t*>(dst) + (i - i0) * (int64_t)kEsm;
+                if (have)
+                    convert_rows(d, srow, kEsm, half_mode);
+                else
+                    std::memset(d, 0, kEsm * sizeof(uint16_t));
+            } else {
+                float* d = static_cast<float*>(dst) + (i - i0) * (int64_t)kEsm;
+                if (have)
+                    std::memcpy(d, srow, kEsm * sizeof(float));
+                else
+                    std::memset(d, 0, kEsm * sizeof(float));
+            }
         }
-    };
-    const int64_t m = i1 - i0;
-    unsigned hw = std::thread::hardware_concurrency();
-    int64_t nt = std::min<int64_t>(std::min<unsigned>(hw ? hw : 1u, 6u), m / 2048);
-    if (nt <= 1) {
-        work(i0, i1);
-        return;
-    }
-    std::vector<std::thread> pool;
-    pool.reserve(nt);
-    const int64_t per = (m + nt - 1) / nt;
-    int64_t done = i0 + per;      // the first slice runs on this thread
-    for (int64_t t = 1; t < nt && done < i1; ++t) {
-        const int64_t a = done, b = std::min(i1, a + per);
-        try {
-            pool.emplace_back(work, a, b);
-        } catch (...) {
-            work(a, i1);
-            done = i1;
-            break;
-        }
-        done = b;
-    }
-    work(i0, std::min(i1, i0 + per));
-    for (auto& th : pool) th.join();
+    });
 }
 
 // grow-only device buffer
@@ -822,6 +915,15 @@ int dptm_set_precision(dptm_handle* h, int mode) try {
     return on_exception("dptm_set_precision");
 }
 
+int dptm_convert_rows(const float* src, int64_t n, int mode, uint16_t* dst) try {
+    if (n < 0 || (n > 0 && (!src || !dst))) return fail(DPTM_EINVAL, "dptm_convert_rows: bad argument");
+    if (mode != kModeBF16 && mode != kModeF16) return fail(DPTM_EINVAL, "dptm_convert_rows: mode must be bf16 (1) or f16 (2)");
+    parallel_slices((size_t)n, (size_t)1 << 20, [=](size_t a, size_t b) { convert_rows(dst + a, src + a, b - a, mode); });
+    return DPTM_OK;
+} catch (...) {
+    return on_exception("dptm_convert_rows");
+}
+
 int dptm_sync(dptm_handle* h) try {
     if (!h) return fail(DPTM_EINVAL, "dptm_sync: NULL handle");
     HIP_TRY(hipSetDevice(h->device));
@@ -987,6 +1089,10 @@ int dptm_score(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const
         std::memcpy(out + c0 * 2, h->pin_out[slot], (size_t)m * 2 * sizeof(float));
         return DPTM_OK;
     };
+    // one-operand half-precision modes: the ESM rows cross PCIe as the mode's 16-bit values (converted while they are
+    // gathered), half the bytes; the split mode and fp32 need the fp32 rows
+    const bool esm_half = h->precision == kModeBF16 || h->precision == kModeF16;
+    const size_t esm_elem = esm_half ? sizeof(uint16_t) : sizeof(float);
     int64_t prev_c0 = 0, prev_m = 0;
     int64_t i = 0;
     for (int64_t c0 = 0; c0 < n; c0 += kChunkSites, ++i) {
@@ -994,18 +1100,21 @@ int dptm_score(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const
         const int slot = (int)(i & 1);
         uint8_t* pin = h->pin_in[slot];
         if (i >= 2) HIP_TRY(hipEventSynchronize(h->ev_copied[slot]));   // the pinned block has crossed PCIe
-        parallel_copy(pin + kPinEsm, esm + c0 * (int64_t)kEsm, (size_t)m * kEsm * sizeof(float));
+        if (esm_half)
+            parallel_convert(reinterpret_cast<uint16_t*>(pin + kPinEsm), esm + c0 * (int64_t)kEsm, m, h->precision);
+        else
+            parallel_copy(pin + kPinEsm, esm + c0 * (int64_t)kEsm, (size_t)m * kEsm * sizeof(float));
         std::memcpy(pin + kPinStruct, strct + c0 * kStruct, (size_t)m * kStruct * sizeof(float));
         for (int b = 0; b < 3; ++b) std::memcpy(pin + pin_tok[b], tk[b] + c0 * kWin[b], (size_t)m * kWin[b]);
         if (i >= 2) HIP_TRY(hipStreamWaitEvent(h->copy_stream, h->ev_scored[slot], 0));   // device slot free again
-        HIP_TRY(hipMemcpyAsync(s_esm[slot], pin + kPinEsm, (size_t)m * kEsm * sizeof(float), hipMemcpyHostToDevice, h->copy_stream));
+        HIP_TRY(hipMemcpyAsync(s_esm[slot], pin + kPinEsm, (size_t)m * kEsm * esm_elem, hipMemcpyHostToDevice, h->copy_stream));
         HIP_TRY(hipMemcpyAsync(s_strct[slot], pin + kPinStruct, (size_t)m * kStruct * sizeof(float), hipMemcpyHostToDevice, h->copy_stream));
         for (int b = 0; b < 3; ++b)
             HIP_TRY(hipMemcpyAsync(s_tok[slot][b], pin + pin_tok[b], (size_t)m * kWin[b], hipMemcpyHostToDevice, h->copy_stream));
         HIP_TRY(hipEventRecord(h->ev_copied[slot], h->copy_stream));
         HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_copied[slot], 0));
         const uint8_t* tok[3] = {s_tok[slot][0], s_tok[slot][1], s_tok[slot][2]};
-        rc = score_chunk(h, h->ws, tok, s_strct[slot], s_esm[slot], kEsm, nullptr, m, s_out[slot], h->stream);
+        rc = score_chunk(h, h->ws, tok, s_strct[slot], s_esm[slot], kEsm, nullptr, m, s_out[slot], h->stream, esm_half);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(h->pin_out[slot], s_out[slot], m * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipEventRecord(h->ev_scored[slot], h->stream));
@@ -1192,21 +1301,24 @@ int dptm_score_proteins(dptm_handle* h, const uint8_t* codes, const int64_t* seq
         std::memcpy(out + c0 * 2, h->pin_out[slot], (size_t)m * 2 * sizeof(float));
         return DPTM_OK;
     };
+    // one-operand half-precision modes: the gathered rows cross PCIe as the mode's 16-bit values
+    const bool esm_half = h->precision == kModeBF16 || h->precision == kModeF16;
+    const size_t esm_elem = esm_half ? sizeof(uint16_t) : sizeof(float);
     int64_t prev_c0 = 0, prev_m = 0, i = 0;
     for (int64_t c0 = 0; c0 < n; c0 += kChunkSites, ++i) {
         const int64_t m = n - c0 < kChunkSites ? n - c0 : kChunkSites;
         const int slot = (int)(i & 1);
         uint8_t* pin = h->pin_in[slot];
         if (i >= 2) HIP_TRY(hipEventSynchronize(h->ev_copied[slot]));   // the pinned block has crossed PCIe
-        gather_esm_rows(reinterpret_cast<float*>(pin + kPinEsm), esm_tables, esm_offsets, positions, site_protein, c0, c0 + m);
+        gather_esm_rows(pin + kPinEsm, esm_tables, esm_offsets, positions, site_protein, c0, c0 + m, esm_half ? h->precision : 0);
         std::memcpy(pin + kPinStruct, strct + c0 * kStruct, (size_t)m * kStruct * sizeof(float));
         if (i >= 2) HIP_TRY(hipStreamWaitEvent(h->copy_stream, h->ev_scored[slot], 0));   // device slot free again
-        HIP_TRY(hipMemcpyAsync(s_esm[slot], pin + kPinEsm, (size_t)m * kEsm * sizeof(float), hipMemcpyHostToDevice, h->copy_stream));
+        HIP_TRY(hipMemcpyAsync(s_esm[slot], pin + kPinEsm, (size_t)m * kEsm * esm_elem, hipMemcpyHostToDevice, h->copy_stream));
         HIP_TRY(hipMemcpyAsync(s_strct[slot], pin + kPinStruct, (size_t)m * kStruct * sizeof(float), hipMemcpyHostToDevice, h->copy_stream));
         HIP_TRY(hipEventRecord(h->ev_copied[slot], h->copy_stream));
         HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_copied[slot], 0));
         if ((rc = assemble(c0, m))) return rc;
-        if ((rc = score_chunk(h, h->ws, tok, s_strct[slot], s_esm[slot], kEsm, nullptr, m, s_out[slot], h->stream))) return rc;
+        if ((rc = score_chunk(h, h->ws, tok, s_strct[slot], s_esm[slot], kEsm, nullptr, m, s_out[slot], h->stream, esm_half))) return rc;
         HIP_TRY(hipMemcpyAsync(h->pin_out[slot], s_out[slot], (size_t)m * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipEventRecord(h->ev_scored[slot], h->stream));
         if (i >= 1 && (rc = retire(slot ^ 1, prev_c0, prev_m))) return rc;

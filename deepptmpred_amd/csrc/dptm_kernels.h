@@ -17,8 +17,9 @@ constexpr int64_t kDenseSmallRows = 512;
 enum PrecisionMode { kModeF32 = 0, kModeBF16 = 1, kModeF16 = 2, kModeF16X3 = 3 };
 
 struct DenseArgs {
-    const float* x;            // [rows][ldx] fp32 activations
-    int64_t ldx;               // floats per row of x
+    const float* x;            // [rows][ldx] fp32 activations (x_half: bfloat16 / float16 values of the mode, 2 bytes each)
+    int64_t ldx;               // elements per row of x
+    int x_half = 0;            // half-precision modes only: x already holds the mode's 16-bit operand values
     const int32_t* row_index;  // optional gather: source row of output row r, <0 = zero row
     int64_t m;                 // output rows
     int k;                     // contraction length, multiple of 8

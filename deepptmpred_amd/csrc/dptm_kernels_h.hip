@@ -841,6 +841,135 @@ __global__ __launch_bounds__(256, 2) void dense_kernel_h(DenseArgs p, const uint
     }
 }
 
+// The same layer when X already holds the mode's 16-bit operand values (rows that crossed PCIe as bfloat16 / float16
+// instead of fp32: half the bytes, and nothing to convert here).  Staged through LDS like dense_kernel_h, 64 inputs
+// per block: a fetch instruction covers whole 128-byte lines (8 lanes per row), the operand fragments are 16-byte
+// reads of the staged rows.  One-operand modes only (the split mode needs fp32 inputs); k a multiple of 64.
+constexpr int kStageStrideH = 72;   // 16-bit values per staged row: 64 + 8 keeps the fragment reads spread over the banks
+
+template <int NT, int EPI, int MODE>
+__global__ __launch_bounds__(256, 2) void dense_kernel_hx(DenseArgs p, const uint4* __restrict__ whi) {
+    static_assert(!HP<MODE>::kSplit, "half inputs carry one operand value each");
+    __shared__ __attribute__((aligned(16))) unsigned short stage_all[4][64 * kStageStrideH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    if (r0 >= p.m) return;
+    unsigned short* stage = stage_all[wave];
+    const int slab = blockIdx.y;
+    const int KS = p.k >> 4, KB = p.k >> 6;
+    const size_t wbase = (size_t)slab * NT * KS * 64 + lane;
+    const unsigned short* xh = reinterpret_cast<const unsigned short*>(p.x);
+
+    // fetch pattern: load i covers rows 8i .. 8i+7 of the tile, lane l -> row 8i + (l >> 3), values 8*(l & 7) .. +7
+    const unsigned short* xsrc[8];
+    bool ok[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int64_t r = r0 + 8 * i + (lane >> 3);
+        if (r > p.m - 1) r = p.m - 1;
+        int64_t src = r;
+        ok[i] = true;
+        if (p.row_index) {
+            const int32_t s = p.row_index[r];
+            ok[i] = s >= 0;
+            src = s >= 0 ? s : 0;
+        }
+        xsrc[i] = xh + src * p.ldx + 8 * (lane & 7);
+    }
+    unsigned short* st_w = stage + (lane >> 3) * kStageStrideH + 8 * (lane & 7);
+    // operand order of a k-step (the chain layout, as make_frag builds it from fp32): the lane of half-wave h takes the
+    // inputs 16 ks + 4h .. + 3 and 16 ks + 8 + 4h .. + 3 -- two 8-byte pieces of the staged row
+    const unsigned short* st_r[2] = {stage + j * kStageStrideH + 4 * h, stage + (32 + j) * kStageStrideH + 4 * h};
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = p.bias[h * (p.n_pad >> 3) + slab * NT * 4 + 4 * t + g];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][t][4 * g + e] = b[e];
+                acc[1][t][4 * g + e] = b[e];
+            }
+        }
+
+    typename HP<MODE>::frag a_n[NT];
+    uint4 xg[8];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) a_n[t] = as_frag<MODE>(whi[wbase + t * KS * 64]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xg[i] = *reinterpret_cast<const uint4*>(xsrc[i]);
+    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint4 z = {0u, 0u, 0u, 0u};
+            *reinterpret_cast<uint4*>(st_w + 8 * i * kStageStrideH) = ok[i] ? xg[i] : z;
+        }
+        if (kb + 1 < KB) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xg[i] = *reinterpret_cast<const uint4*>(xsrc[i] + 64 * (kb + 1));
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int ks = 4 * kb + kk;
+            typename HP<MODE>::frag a[NT], b[2];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a[t] = a_n[t];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint2 lo = *reinterpret_cast<const uint2*>(st_r[i] + 16 * kk), hi = *reinterpret_cast<const uint2*>(st_r[i] + 16 * kk + 8);
+                b[i] = as_frag<MODE>(uint4{lo.x, lo.y, hi.x, hi.y});
+            }
+            if (ks + 1 < KS) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) a_n[t] = as_frag<MODE>(whi[wbase + (t * KS + ks + 1) * 64]);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[0][t] = mfma16(a[t], b[0], acc[0][t]);
+                acc[1][t] = mfma16(a[t], b[1], acc[1][t]);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t r = r0 + 32 * i + j;
+        if (r >= p.m) continue;
+        float* orow = p.out + r * p.ldo + p.col_off + slab * NT * 32 + 4 * h;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {acc[i][t][4 * g], acc[i][t][4 * g + 1], acc[i][t][4 * g + 2], acc[i][t][4 * g + 3]};
+                const int vi = h * (p.n_pad >> 3) + slab * NT * 4 + 4 * t + g;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = swish_h(v[e]);
+                if (EPI == kEpiSwishAffine) {
+                    const f32x4 sc = p.scale[vi], sh = p.shift[vi];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+                }
+                *reinterpret_cast<f32x4*>(orow + 32 * t + 8 * g) = v;
+            }
+    }
+}
+
+template <int MODE>
+static hipError_t launch_dense_hx_m(const DenseArgs& a, int epi, const void* whi, hipStream_t st) {
+    const unsigned gx = (unsigned)((a.m + 255) / 256), gy = (unsigned)(a.n_pad / 128);
+    const uint4* hi = reinterpret_cast<const uint4*>(whi);
+    if (epi == kEpiSwish)
+        hipLaunchKernelGGL((dense_kernel_hx<4, kEpiSwish, MODE>), dim3(gx, gy), dim3(256), 0, st, a, hi);
+    else if (epi == kEpiSwishAffine)
+        hipLaunchKernelGGL((dense_kernel_hx<4, kEpiSwishAffine, MODE>), dim3(gx, gy), dim3(256), 0, st, a, hi);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 template <int MODE>
 static hipError_t launch_dense_h_m(const DenseArgs& a, int epi, const void* whi, const void* wlo, hipStream_t st) {
     const unsigned gx = (unsigned)((a.m + 255) / 256), gy = (unsigned)(a.n_pad / 128);
@@ -866,6 +995,14 @@ static hipError_t launch_dense_h_m(const DenseArgs& a, int epi, const void* whi,
 hipError_t launch_dense_h(int mode, const DenseArgs& a, int epi, const void* whi, const void* wlo, hipStream_t st) {
     if (a.m == 0) return hipSuccess;
     if (a.n_pad % 128 != 0 || a.k % 32 != 0) return hipErrorInvalidValue;
+    if (a.x_half) {      // 16-bit inputs: one-operand modes, rows of 8-value groups on 16-byte boundaries
+        if (a.k % 64 != 0 || a.ldx % 8 != 0 || (reinterpret_cast<uintptr_t>(a.x) & 15) != 0) return hipErrorInvalidValue;
+        switch (mode) {
+            case kModeBF16: return launch_dense_hx_m<kModeBF16>(a, epi, whi, st);
+            case kModeF16: return launch_dense_hx_m<kModeF16>(a, epi, whi, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (mode) {
         case kModeBF16: return launch_dense_h_m<kModeBF16>(a, epi, whi, wlo, st);
         case kModeF16: return launch_dense_h_m<kModeF16>(a, epi, whi, wlo, st);

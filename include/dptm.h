@@ -174,6 +174,13 @@ int dptm_assemble_proteins_device(dptm_handle* h, const uint8_t* codes, const in
                                   const int32_t* site_protein, int64_t n, uint8_t* tok21, uint8_t* tok33,
                                   uint8_t* tok51, int32_t* esm_row, void* stream);
 
+/* fp32 -> the 16-bit operand values of a one-operand half-precision mode (mode 1 = bfloat16, 2 = float16; round to
+ * nearest even, the kernels' own conversion), n values, on a few host threads; no GPU involved.  This is what the
+ * host-buffer entry points (dptm_score, dptm_score_proteins) do to the ESM rows of a call larger than one pass while
+ * they gather them into pinned memory in those modes, so that the rows cross PCIe at 2 bytes per value: results are
+ * bit-identical to converting on the device.  No counterpart in the reference (Keras feeds fp32, predict.py:598-599). */
+int dptm_convert_rows(const float* src, int64_t n, int mode, uint16_t* dst);
+
 /* Blocks until everything enqueued on the handle's own stream has finished. */
 int dptm_sync(dptm_handle* h);
 

@@ -31,9 +31,9 @@ if [ "$what" = score ]; then
 elif [ "$what" = train ]; then
   export DPTM_TRAIN_SERIAL=1
   for batch in 8192 64; do
-    B="python3 $repo/bench.py --train --batch $batch --steps 20 --warmup 3"
+    B="python3 $repo/bench.py --train --batch $batch --steps 20 --warmup 3 --no-cpu-baseline"
     timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/train_trace_b$batch -- $B > $out/train_trace_b$batch.json 2> $out/train_trace_b$batch.log
-    B="python3 $repo/bench.py --train --batch $batch --steps 3 --warmup 1"
+    B="python3 $repo/bench.py --train --batch $batch --steps 3 --warmup 1 --no-cpu-baseline"
     timeout -s KILL 180 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/train_fetch_b$batch -- $B > $out/train_fetch_b$batch.json 2> $out/train_fetch_b$batch.log
     timeout -s KILL 180 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/train_write_b$batch -- $B > $out/train_write_b$batch.json 2> $out/train_write_b$batch.log
     timeout -s KILL 180 rocprofv3 --pmc $ISSUE --output-format csv -d $out/train_mfma_b$batch -- $B > $out/train_mfma_b$batch.json 2> $out/train_mfma_b$batch.log

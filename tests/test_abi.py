@@ -152,3 +152,33 @@ def test_null_handles_and_arguments_are_refused():
     lib.dptm_trainer_destroy(None)
     assert lib.dptm_trainer_param_floats(None) == 0
     assert lib.dptm_create(None, 0, None, 0, None) == _native.DPTM_EINVAL
+
+
+def test_host_conversion_rounds_like_the_device():
+    """dptm_convert_rows: fp32 -> bfloat16 / float16 bit patterns, round to nearest even, against torch's CPU casts
+    (the same IEEE conversions the kernels' v_cvt instructions perform): normal values, ties, subnormal halves,
+    overflow to infinity, signed zeros; a length that leaves a scalar tail behind the vector loop."""
+    import torch
+    rng = np.random.default_rng(5)
+    x = np.concatenate([
+        rng.normal(0, 0.27, 100003), rng.normal(0, 1e-6, 5000), rng.normal(0, 3e4, 5000), rng.uniform(-7e-5, 7e-5, 5000),
+        np.array([0.0, -0.0, 1.0, -1.0, 65504.0, 65519.9, 65520.0, 1e38, -1e38, 5.96e-8, 2.98e-8, 2.9802325e-08, 6.1e-5]),
+        np.float32(1.0) + np.arange(64, dtype=np.float32) * np.float32(2.0 ** -9),       # bf16 ties and near-ties
+        np.float32(1.0) + np.arange(64, dtype=np.float32) * np.float32(2.0 ** -12),      # f16 ties and near-ties
+    ]).astype(np.float32)
+    t = torch.from_numpy(x)
+    want_bf = t.to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    want_h = t.to(torch.float16).view(torch.int16).numpy().view(np.uint16)
+    assert np.array_equal(_native.convert_rows(x, "bf16"), want_bf)
+    assert np.array_equal(_native.convert_rows(x, "f16"), want_h)
+    # pieces shorter than a vector register go through the scalar code alone
+    sub = np.concatenate([x[:3000], x[100003:104000], x[-141:]])
+    for mode, want in (("bf16", t.to(torch.bfloat16)), ("f16", t.to(torch.float16))):
+        ref = np.concatenate([want.view(torch.int16).numpy().view(np.uint16)[:3000],
+                              want.view(torch.int16).numpy().view(np.uint16)[100003:104000],
+                              want.view(torch.int16).numpy().view(np.uint16)[-141:]])
+        got = np.concatenate([_native.convert_rows(sub[i:i + 7], mode) for i in range(0, len(sub), 7)])
+        assert np.array_equal(got, ref), mode
+    assert _native.convert_rows(np.zeros((0, 4), np.float32), "bf16").shape == (0, 4)
+    with pytest.raises(ValueError):
+        _native.convert_rows(x, "f16x3")

@@ -94,3 +94,50 @@ def test_mode_switch_round_trip(model, weights):
     assert np.array_equal(model.predict(x), a)
     with pytest.raises(ValueError):
         model.scorer.set_precision("fp8")
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+def test_host_pipeline_sends_half_rows_and_scores_alike(model, mode):
+    """A host-array call larger than one pass sends the ESM rows over PCIe as the mode's 16-bit values (converted on
+    the host, round to nearest even): every probability equals, bit for bit, what the device-resident call gives for
+    the fp32 rows (which the kernel rounds itself).  Three passes with a ragged tail.  The many-proteins entry point takes the same path for its gathered rows."""
+    import torch
+    sc = model.scorer
+    sc.set_precision(mode)
+    c = sc.chunk_sites
+    n = 2 * c + 1333      # (a last pass of at most 512 sites would take the small-call kernels, whose dense layers stay fp32)
+    small = spec.synthetic_inputs(4096, 93)
+    small[4][5, :6] = [0.0, -0.0, 65519.0, 1e-7, 3e-8, 1.0009765625]      # ties, subnormal halves, the largest half
+    reps = -(-n // 4096)
+    x = [np.tile(a, (reps, 1))[:n].copy() for a in small]
+    p = model.predict(x)                                   # pipeline: half rows over PCIe
+    # the device-resident call on the same rows walks the same passes and tiles (a site's place in its tile decides
+    # the order of the attention sums in these modes) and rounds the fp32 rows itself
+    dev = torch.device("cuda:0")
+    d = [torch.from_numpy(a).to(dev) for a in x]
+    out = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    sc.score_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), n,
+                    out.data_ptr(), 0)
+    sc.sync()
+    assert np.isfinite(p).all() and np.array_equal(p, out.cpu().numpy())
+    del d, out
+    # many proteins per call: 40,000 sites of 200 proteins, rows gathered (and converted) by the host, against the
+    # device-resident form of the same call (tables resident as fp32, rows gathered inside the ESM layer)
+    from deepptmpred_amd.model import encode_sequence
+    L, P, per = 300, 200, 200
+    rng = np.random.default_rng(7)
+    codes = np.concatenate([encode_sequence("".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWY"), L))) for _ in range(P)])
+    tables = rng.normal(0, 0.27, (P * L, 1280)).astype(np.float32)
+    offs = np.arange(P + 1, dtype=np.int64) * L
+    pos = np.concatenate([np.sort(rng.choice(np.arange(1, L + 1), per, replace=False)) for _ in range(P)]).astype(np.int32)
+    prot = np.repeat(np.arange(P, dtype=np.int32), per)
+    st = np.ascontiguousarray(np.tile(O.DEFAULT_STRUCT_ROW, (P * per, 1)), dtype=np.float32)
+    got = sc.score_proteins(codes, offs, tables, offs.copy(), pos, prot, st)
+    dv = [torch.from_numpy(a).to(dev) for a in (codes, offs, tables, offs.copy(), pos, prot, st)]
+    out = torch.empty((P * per, 2), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    sc.score_proteins_device(dv[0].data_ptr(), dv[1].data_ptr(), dv[2].data_ptr(), dv[3].data_ptr(), P, dv[4].data_ptr(),
+                             dv[5].data_ptr(), dv[6].data_ptr(), P * per, out.data_ptr(), 0)
+    sc.sync()
+    assert np.isfinite(got).all() and np.array_equal(got, out.cpu().numpy())
