@@ -387,10 +387,12 @@ __global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P
 // ------------------------------------------------------------------------------------
 // Per-site dense layer: out[r][col_off + n] = epi(sum_k X[src(r)][k] * Wt[k][n] + b[n]).
 // One wavefront computes 64 rows x (NT*32) columns; a workgroup = 4 wavefronts = 256
-// rows of one column slab (blockIdx.y), so its wavefronts share the weight stream.
+// rows of one column slab (blockIdx.y), so its wavefronts share the weight stream.  Two workgroups
+// per CU (launch bound): without the bound the compiler takes 154 + 128 accumulator registers, one
+// wavefront per SIMD; with it 190 and none spilled, and the layers run 3-5 % faster.
 // ------------------------------------------------------------------------------------
 template <int NT, int EPI>
-__global__ __launch_bounds__(256) void dense_kernel(DenseArgs p) {
+__global__ __launch_bounds__(256, 2) void dense_kernel(DenseArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, j = lane & 31;
     const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 64;

@@ -14,6 +14,8 @@
 // come from the LDS image of the tile, masked at the site edges (Keras pads with zeros per window).
 #include <hip/hip_runtime.h>
 
+#define DPTM_KEEP_INDEX_LOCAL 1   // see dptm_mfma.h: table addresses are formed where they are used
+
 #include "dptm_layout.h"
 #include "dptm_mfma.h"
 #include "dptm_train_device.h"
