@@ -62,7 +62,12 @@ int on_exception(const char* where) noexcept {
     } while (0)
 
 constexpr double kBnEps = 1e-3;  // keras BatchNormalization default epsilon
-constexpr int64_t kChunkSites = 32768;
+constexpr int64_t kChunkSites = 32768;    // sites per pass of the host-buffer entry points (size of their staging slots)
+// Sites per pass of the device-resident entry points.  A branch kernel holds one workgroup per CU (its LDS), so a
+// launch runs in rounds of 256 tiles and the last round is partly empty; 107,520 = 84 x 5 x 256 = 60 x 7 x 256 =
+// 35 x 12 x 256 sites fill whole rounds of all three window sizes (5 / 7 / 12 sites per tile), and a launch three
+// times as long loses a third as much to its ragged end: 3.61e6 -> 3.68e6 sites/s over a million resident sites.
+constexpr int64_t kPassSites = 107520;
 
 // ---- host-side packing into the layouts of dptm_layout.h
 
@@ -197,7 +202,8 @@ struct dptm_handle {
     std::vector<float> blob;              // canonical weights, kept to build the half-precision images on demand
     bool half_ready = false;
     DenseLayer strct, esm1, esm2, t1, t2, head;
-    Workspace ws;                         // per-chunk workspace (kChunkSites rows)
+    Workspace ws;                         // per-pass workspace (ws_cap rows: kChunkSites, or kPassSites once a call needed more)
+    int64_t ws_cap = 0;
     bool plain = false;                   // set for the duration of a call that may create no stream or event
     float* d_zero_row = nullptr;
     // per-chunk staging for assembled windows
@@ -481,6 +487,28 @@ int score_chunk(dptm_handle* h, const Workspace& ws, const uint8_t* const tok[3]
                         DPTM_PROF_TRUNK2)))
         return rc;
     return run_dense(h, h->head, kEpiHead, ws.t2, kT2, nullptr, m, out, 2, 0, st, DPTM_PROF_HEAD);
+}
+
+// Per-pass device buffers (activations of the per-site layers, assembled windows, ESM row indices) for passes of up to
+// `sites` sites: kChunkSites rows from dptm_create on, kPassSites rows from the first call that scores more than that
+// in one go (grow-only; the old buffers are released once nothing can be using them).
+int ensure_workspace(dptm_handle* h, int64_t sites) {
+    if (sites <= h->ws_cap) return DPTM_OK;
+    const int64_t cap = sites > kChunkSites ? kPassSites : kChunkSites;
+    if (h->ws_cap) HIP_TRY(hipDeviceSynchronize());
+    void** bufs[] = {(void**)&h->ws.concat, (void**)&h->ws.h1, (void**)&h->ws.t1, (void**)&h->ws.t2, (void**)&h->d_tok[0],
+                     (void**)&h->d_tok[1], (void**)&h->d_tok[2], (void**)&h->d_esm_row};
+    const size_t bytes[] = {cap * (size_t)kConcat * 4, cap * (size_t)kEsm1 * 4, cap * (size_t)kT1 * 4, cap * (size_t)kT2 * 4,
+                            cap * (size_t)kWin[0], cap * (size_t)kWin[1], cap * (size_t)kWin[2], cap * sizeof(int32_t)};
+    h->ws_cap = 0;
+    for (int i = 0; i < 8; ++i) {
+        if (*bufs[i]) (void)hipFree(*bufs[i]);
+        *bufs[i] = nullptr;
+    }
+    for (int i = 0; i < 8; ++i)
+        if (hipMalloc(bufs[i], bytes[i]) != hipSuccess) return fail(DPTM_ENOMEM, "device allocation of the per-pass workspace failed");
+    h->ws_cap = cap;
+    return DPTM_OK;
 }
 
 int ensure_host_staging(dptm_handle* h) {
@@ -868,10 +896,7 @@ int dptm_create(const void* weights, size_t nbytes, const dptm_spec* spec, int d
         if (hipMalloc(p, bytes) != hipSuccess) return fail(DPTM_ENOMEM, "dptm_create: device allocation failed");
         return DPTM_OK;
     };
-    if ((rc = dalloc((void**)&h->ws.concat, kChunkSites * (size_t)kConcat * 4))) return bail(rc);
-    if ((rc = dalloc((void**)&h->ws.h1, kChunkSites * (size_t)kEsm1 * 4))) return bail(rc);
-    if ((rc = dalloc((void**)&h->ws.t1, kChunkSites * (size_t)kT1 * 4))) return bail(rc);
-    if ((rc = dalloc((void**)&h->ws.t2, kChunkSites * (size_t)kT2 * 4))) return bail(rc);
+    if ((rc = ensure_workspace(h, 1))) return bail(rc);
     if (device >= kMaxDevices) return bail(fail(DPTM_EINVAL, "dptm_create: device index beyond the library's table"));
     if (!g_scratch_ptr[device]) {     // this device's copy of the static workspace (device `device` is current)
         float* sp = nullptr;
@@ -884,9 +909,6 @@ int dptm_create(const void* weights, size_t nbytes, const dptm_spec* spec, int d
         return bail(fail(DPTM_EHIP, std::string("dptm_create: kernel set-up failed: ") + hipGetErrorString(e)));
     if ((rc = dalloc((void**)&h->d_zero_row, kEsm * 4))) return bail(rc);
     if (hipMemset(h->d_zero_row, 0, kEsm * 4) != hipSuccess) return bail(fail(DPTM_EHIP, "hipMemset failed"));
-    for (int b = 0; b < 3; ++b)
-        if ((rc = dalloc((void**)&h->d_tok[b], kChunkSites * (size_t)kWin[b]))) return bail(rc);
-    if ((rc = dalloc((void**)&h->d_esm_row, kChunkSites * sizeof(int32_t)))) return bail(rc);
     if (hipDeviceSynchronize() != hipSuccess) return bail(fail(DPTM_EHIP, "dptm_create: device sync failed"));
     *out = owner.release();
     return DPTM_OK;
@@ -944,9 +966,10 @@ int dptm_score_device(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33
     if (misaligned(strct, 16) || misaligned(esm, 16) || misaligned(out, 8))
         return fail(DPTM_EINVAL, "dptm_score_device: struct / esm must be 16-byte aligned, out 8-byte aligned");
     HIP_TRY(hipSetDevice(h->device));
+    if (int rc = ensure_workspace(h, std::min(n, kPassSites))) return rc;
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
-    for (int64_t c0 = 0; c0 < n; c0 += kChunkSites) {
-        const int64_t m = n - c0 < kChunkSites ? n - c0 : kChunkSites;
+    for (int64_t c0 = 0; c0 < n; c0 += kPassSites) {
+        const int64_t m = n - c0 < kPassSites ? n - c0 : kPassSites;
         const uint8_t* tok[3] = {tok21 + c0 * 21, tok33 + c0 * 33, tok51 + c0 * 51};
         int rc = score_chunk(h, h->ws, tok, strct + c0 * kStruct, esm + c0 * (int64_t)kEsm, kEsm, nullptr, m,
                              out + c0 * 2, st);
@@ -1036,8 +1059,9 @@ int dptm_score_protein_device(dptm_handle* h, const uint8_t* codes, int64_t L, c
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
     const float* table = esm_rows > 0 ? esm_table : h->d_zero_row;
-    for (int64_t c0 = 0; c0 < n; c0 += kChunkSites) {
-        const int64_t m = n - c0 < kChunkSites ? n - c0 : kChunkSites;
+    if (int rc = ensure_workspace(h, std::min(n, kPassSites))) return rc;
+    for (int64_t c0 = 0; c0 < n; c0 += kPassSites) {
+        const int64_t m = n - c0 < kPassSites ? n - c0 : kPassSites;
         int rc = dptm_assemble_device(h, codes, L, esm_rows, positions + c0, m, h->d_tok[0], h->d_tok[1],
                                       h->d_tok[2], h->d_esm_row, st);
         if (rc) return rc;
@@ -1229,8 +1253,9 @@ int dptm_score_proteins_device(dptm_handle* h, const uint8_t* codes, const int64
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : h->stream;
     // esm_tables == NULL: the caller states that no protein has a table (all esm_offsets equal), so no row is read
     const float* table = esm_tables ? esm_tables : h->d_zero_row;
-    for (int64_t c0 = 0; c0 < n; c0 += kChunkSites) {
-        const int64_t m = n - c0 < kChunkSites ? n - c0 : kChunkSites;
+    if (int rc = ensure_workspace(h, std::min(n, kPassSites))) return rc;
+    for (int64_t c0 = 0; c0 < n; c0 += kPassSites) {
+        const int64_t m = n - c0 < kPassSites ? n - c0 : kPassSites;
         int rc = dptm_assemble_proteins_device(h, codes, seq_offsets, esm_offsets, positions + c0, site_protein + c0, m,
                                                h->d_tok[0], h->d_tok[1], h->d_tok[2], h->d_esm_row, st);
         if (rc) return rc;

@@ -220,7 +220,10 @@ int dptm_profile_end(dptm_handle* h, float* ms, int64_t* launches);
 #define DPTM_PREC_F16X3 3
 int dptm_set_precision(dptm_handle* h, int mode);
 
-/* Largest number of sites the device-resident calls process per internal pass. */
+/* Sites per internal pass of the HOST-buffer calls (dptm_score, dptm_score_protein, dptm_score_proteins): 32,768, the
+ * size of their staging slots.  The device-resident calls walk their sites in passes of 107,520 (whole rounds of
+ * tiles for all three window sizes); their per-pass buffers grow to that size on the first call that scores more
+ * than 32,768 sites at once (one allocation, kept). */
 int64_t dptm_chunk_sites(const dptm_handle* h);
 
 const char* dptm_last_error(void);

@@ -111,14 +111,17 @@ def test_host_pipeline_sends_half_rows_and_scores_alike(model, mode):
     reps = -(-n // 4096)
     x = [np.tile(a, (reps, 1))[:n].copy() for a in small]
     p = model.predict(x)                                   # pipeline: half rows over PCIe
-    # the device-resident call on the same rows walks the same passes and tiles (a site's place in its tile decides
-    # the order of the attention sums in these modes) and rounds the fp32 rows itself
+    # the device-resident call rounds the fp32 rows itself; it is made once per pass of the host pipeline, so that
+    # every site sits at the same place of its tile in both (that place decides the order of the attention sums
+    # in these modes)
     dev = torch.device("cuda:0")
     d = [torch.from_numpy(a).to(dev) for a in x]
     out = torch.empty((n, 2), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
-    sc.score_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), n,
-                    out.data_ptr(), 0)
+    for c0 in range(0, n, c):
+        m_ = min(c, n - c0)
+        sc.score_device(d[0][c0:].data_ptr(), d[1][c0:].data_ptr(), d[2][c0:].data_ptr(), d[3][c0:].data_ptr(),
+                        d[4][c0:].data_ptr(), m_, out[c0:].data_ptr(), 0)
     sc.sync()
     assert np.isfinite(p).all() and np.array_equal(p, out.cpu().numpy())
     del d, out
@@ -137,7 +140,9 @@ def test_host_pipeline_sends_half_rows_and_scores_alike(model, mode):
     dv = [torch.from_numpy(a).to(dev) for a in (codes, offs, tables, offs.copy(), pos, prot, st)]
     out = torch.empty((P * per, 2), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
-    sc.score_proteins_device(dv[0].data_ptr(), dv[1].data_ptr(), dv[2].data_ptr(), dv[3].data_ptr(), P, dv[4].data_ptr(),
-                             dv[5].data_ptr(), dv[6].data_ptr(), P * per, out.data_ptr(), 0)
+    for c0 in range(0, P * per, c):
+        m_ = min(c, P * per - c0)
+        sc.score_proteins_device(dv[0].data_ptr(), dv[1].data_ptr(), dv[2].data_ptr(), dv[3].data_ptr(), P,
+                                 dv[4][c0:].data_ptr(), dv[5][c0:].data_ptr(), dv[6][c0:].data_ptr(), m_, out[c0:].data_ptr(), 0)
     sc.sync()
     assert np.isfinite(got).all() and np.array_equal(got, out.cpu().numpy())
