@@ -137,6 +137,7 @@ struct dptm_trainer {
         f32x4_tr *dx1 = nullptr, *dz1 = nullptr;   // chain-tiled gradients handed from one backward kernel to the next
         float* bnsums_all = nullptr;
         float* part = nullptr;            // partial parameter gradients of the fused backward kernel, one slab per workgroup
+        float* row_part = nullptr;        // the same for the row-wise launches of a large batch: [2 blocks][kRowMaxParts][kRowPartStride]
     };
     Scratch sc[4];                        // [0..2] sequence branches, [3] per-site layers (BatchNorm sums only)
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
@@ -219,7 +220,8 @@ int alloc_acts(dptm_trainer* t) {
         if (b == 3) break;
         const size_t RP = (size_t)t_tile_rows_max(B, kW[b]);
         float *d1 = nullptr, *d2 = nullptr;
-        ok &= need(d1, RP * 64) && need(d2, RP * 64) && need(s.part, (size_t)kTbMaxParts * kTbPartStride);
+        ok &= need(d1, RP * 64) && need(d2, RP * 64) && need(s.part, (size_t)kTbMaxParts * kTbPartStride) &&
+              need(s.row_part, (size_t)2 * kRowMaxParts * kRowPartStride);
         s.dx1 = reinterpret_cast<f32x4_tr*>(d1);
         s.dz1 = reinterpret_cast<f32x4_tr*>(d2);
     }
@@ -235,6 +237,7 @@ size_t arena_bytes(int64_t B) {
         f += RP * 64 * 3;                                           // conv block activations
         f += 2 * (RP * 64 * 6 + RP * 8 + RP * 4) + RP * 4;          // saved TransformerBlock activations, pooling
         f += RP * 64 * 2 + (size_t)kTbMaxParts * kTbPartStride;     // gradient hand-over, partial gradients
+        f += (size_t)2 * kRowMaxParts * kRowPartStride;             // partial gradients of the row-wise launches
     }
     f += (size_t)B * (128 * 2 + 512 * 3 + 256 + 576 + 512 * 3 + 256 * 3 + 2);
     f += (4 + 2 * 10) * 1024 + 64 + (size_t)B * (576 + 1024 + 512 + 128);
@@ -463,6 +466,14 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
         f.stream_base = (unsigned)(b * 8 + 2);
         f.thr = dropout_threshold(rt.tb);
         f.scale = rt.tb > 0.f ? 1.0f / (1.0f - rt.tb) : 1.0f;
+        // the split form of large batches: second hand-over array (idle until the convolutions go backward), partial
+        // buffers of the row-wise launches, five more tile counters behind the nine of tile_queue
+        f.blk = 0;
+        f.gin = nullptr;
+        f.gout = nullptr;
+        f.dtmp = c.s->dz1;
+        f.row_part = c.s->row_part;
+        f.queues = reinterpret_cast<unsigned*>(t->d_loss + 32) + 9 + b * 5;
         TbGrads g;
         for (int i = 0; i < 2; ++i) {
             const TbP& w = p.tb[i];

@@ -89,58 +89,62 @@ hipError_t t_pack(const PackJob* jobs_dev, int n_jobs, float lambda, unsigned* s
 
 namespace {
 struct Cand { int S, NW; };
-// candidates per window size, largest tile first; NW in {1, 2, 4, 8} so that the weight-gradient blocks divide evenly
-// The last entry serves batches too small for any other: one site in FOUR wavefronts.  The wavefronts without rows
-// of their own take a share of every weight-gradient unit (whose contraction stops at the site's last row), so the
-// dependent chain of the wavefronts that do hold rows -- which is what such a launch lasts -- gets shorter.
-const Cand kCand21[] = {{12, 8}, {6, 4}, {3, 2}, {1, 1}, {1, 4}};
-const Cand kCand33[] = {{7, 8}, {3, 4}, {1, 2}, {1, 4}};
-const Cand kCand51[] = {{5, 8}, {2, 4}, {1, 2}, {1, 4}};
-// take the largest tile that still gives this many workgroups (DPTM_TRAIN_MIN_TILES overrides: tests use it to
-// run the large tiles on small batches)
-int64_t min_tiles() {
-    static const int64_t v = [] {
-        const char* e = std::getenv("DPTM_TRAIN_MIN_TILES");
-        const long long x = e ? std::atoll(e) : 0;
-        return (int64_t)(x >= 1 ? x : 192);
+// Tiles per window size: whole sites in eight wavefronts, in four, and one site spread over FOUR wavefronts.  In the
+// last one the wavefronts without rows of their own take a share of every weight-gradient unit (whose contraction
+// stops at the site's last row), so the dependent chain of the wavefronts that do hold rows -- which is what such a
+// launch lasts -- gets shorter.
+const Cand kCand21[] = {{12, 8}, {6, 4}, {1, 4}};
+const Cand kCand33[] = {{7, 8}, {3, 4}, {1, 4}};
+const Cand kCand51[] = {{5, 8}, {2, 4}, {1, 4}};
+constexpr int kNumCand = 3;
+constexpr int kCUs = 256;
+
+int64_t tiles_of(const Cand& c, int64_t n) { return (n + c.S - 1) / c.S; }
+// workgroups of the three branches together (they run side by side on three streams, one workgroup per CU: a
+// four-wavefront tile holds 91 KB of LDS)
+int64_t workgroups_all(int i, int64_t n) { return tiles_of(kCand21[i], n) + tiles_of(kCand33[i], n) + tiles_of(kCand51[i], n); }
+// one round: every workgroup of the three branches finds a CU at once.  The four-wavefront tiles stop a little
+// short of the chip (measured: at 255 sites = 256 workgroups they are already 5 % behind the eight-wavefront tiles).
+bool one_round(int i, int64_t n) { return workgroups_all(i, n) <= (i == 2 ? kCUs : kCUs - 24); }
+
+// DPTM_TRAIN_TILE=i pins candidate i (measurements: tools/tile_sweep.sh; tests of a tile shape on a small batch)
+int forced_tile() {
+    static const int v = [] {
+        const char* e = std::getenv("DPTM_TRAIN_TILE");
+        const int x = e ? std::atoi(e) : -1;
+        return x >= kNumCand ? kNumCand - 1 : x;
     }();
     return v;
 }
 }  // namespace
 
-// batches up to this many sites take the last candidate: the three branches' workgroups (one per CU: a four-wavefront
-// tile holds 91 KB of LDS) then still run side by side on the chip's 256 CUs
-constexpr int64_t kLatencyTileSites = 85;
-
+// A launch of these kernels lasts about as long as ONE tile's dependent chain times the rounds of tiles a CU sees,
+// and the chain of an eight-wavefront tile is only ~1.65x that of a four-wavefront tile that holds less than half
+// the sites.  So: the smallest tile whose workgroups -- of all three branches -- are on the chip at once (one round),
+// else the largest.  Measured per step (MI355X): 128 sites 0.81 ms with four-wavefront tiles against 1.02 with eight;
+// 256 sites 1.10 ms with eight against 1.17 with four; 512 sites 1.36 against 1.56.
 TileCfg t_tile_cfg(int64_t n, int wlen) {
     const Cand* c = wlen == 21 ? kCand21 : wlen == 33 ? kCand33 : kCand51;
-    const int nc = wlen == 21 ? 5 : 4;
-    const int fallback = n <= kLatencyTileSites ? nc - 1 : nc - 2;
-    TileCfg r{c[fallback].S, c[fallback].NW, 0};
-    for (int i = 0; i < nc - 1; ++i)
-        if ((n + c[i].S - 1) / c[i].S >= min_tiles()) {
-            r.S = c[i].S;
-            r.NW = c[i].NW;
-            break;
-        }
-    r.ntiles = (n + r.S - 1) / r.S;
+    int i = forced_tile();
+    if (i < 0) i = one_round(2, n) ? 2 : one_round(1, n) ? 1 : 0;
+    TileCfg r{c[i].S, c[i].NW, 0};
+    r.ntiles = tiles_of(c[i], n);
     return r;
 }
 
 int64_t t_tile_rows_max(int64_t max_sites, int wlen) {
-    // the padded row count grows with n inside one (S, NW) regime: its maximum sits at a regime's upper end
-    const Cand* c = wlen == 21 ? kCand21 : wlen == 33 ? kCand33 : kCand51;
-    const int nc = wlen == 21 ? 5 : 4;
+    // the padded row count grows with n inside one tile regime: its maximum sits at a regime's upper end
     int64_t best = 0;
-    for (int i = 0; i < nc; ++i) {
-        // largest n (<= max_sites) that still selects candidate i: below the threshold of every larger tile
-        int64_t hi = max_sites;
-        if (i == nc - 1)
-            hi = hi < kLatencyTileSites ? hi : kLatencyTileSites;
-        else if (i > 0)
-            hi = hi < (min_tiles() - 1) * c[i - 1].S ? hi : (min_tiles() - 1) * c[i - 1].S;
-        if (hi < 1) continue;
-        const TileCfg t = t_tile_cfg(hi, wlen);
+    for (int i = 0; i < kNumCand; ++i) {
+        int64_t lo = 1, hi = max_sites;       // largest n <= max_sites whose three branches fit the chip with candidate i
+        if (i > 0) {
+            if (!one_round(i, 1)) continue;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi + 1) / 2;
+                if (one_round(i, mid)) lo = mid; else hi = mid - 1;
+            }
+        }
+        const TileCfg t = t_tile_cfg(i > 0 ? lo : max_sites, wlen);
         const int64_t rows = t.ntiles * t.NW * 32;
         best = rows > best ? rows : best;
     }
@@ -430,7 +434,10 @@ static_assert(kSPoolB < kTbVecs, "vector slots");
 
 // MAXT: the largest workgroup the instance is launched with.  Tiles of up to four wavefronts get an instance of their
 // own whose register budget is twice that of the eight-wavefront tile (one wavefront per SIMD instead of two).
-template <int W, int MAXT>
+// MODE 0: the whole backward pass of both blocks and the pooling in one launch.  Large batches split it (see TbBwdArgs):
+// MODE 1 = the pooling alone, MODE 2 = the attention half of block p.blk (output projection, attention, Q / K / V); the
+// row-wise half of a block runs in tb_row_bwd_kernel between them.
+template <int W, int MAXT, int MODE>
 __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int NW = blockDim.x >> 6, rows_tile = NW * 32;
@@ -480,7 +487,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
         f32x4 dy[8];   // gradient w.r.t. the output of the block in hand
         TB_SYNC();   // the previous tile's last exchange through xreg has been read
         // ---- attention pooling backward: dx_t = alpha_t dout + dz_t w, dz_t = alpha_t (dalpha_t - sum alpha dalpha)(1 - a_t^2)
-        {
+        if (MODE != 2) {
             const f32x4* tv1 = p.P + kOffTb + kTbSize + kTbVec;
             const f32x4* pv = p.P + kOffPoolV;
             f32x4 x[8];
@@ -523,8 +530,15 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
             TB_SYNC();   // the scores in xreg have been read
         }
         PH_MARK(0)   // pooling backward
+        if (MODE == 1) {       // the pooling alone: its input gradient goes to the row-wise kernel of block 1
+#pragma unroll
+            for (int u = 0; u < 8; ++u) AT4(p.gout, u) = dy[u];
+            first = false;
+            continue;
+        }
+        const int blk_hi = MODE == 2 ? p.blk : 1, blk_lo = MODE == 2 ? p.blk : 0;
 #pragma unroll 1
-        for (int blk = 1; blk >= 0; --blk) {
+        for (int blk = blk_hi; blk >= blk_lo; --blk) {
             const f32x4* T = p.P + kOffTb + blk * kTbSize;
             const f32x4* tv = T + kTbVec;
             const f32x4* TT = p.PT + blk * kBtSize;
@@ -534,6 +548,11 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
             const f32x2 iv = AT1(sv.inv);
             // ---- LayerNorm 2 backward: dy -> dsum = d(h + f2)
             f32x4 dsum[8];
+            if (MODE == 2) {   // the row-wise half ran in tb_row_bwd_kernel: d(x + attention output) arrives in p.din
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dsum[u] = AT4(p.gin, u);
+            }
+            if (MODE == 0) {
             {
                 f32x4 xh[8];
 #pragma unroll
@@ -622,6 +641,7 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
                 wave_fence();
             }
             PH_MARK(4)   // LayerNorm 1 backward
+            }   // MODE == 0: row-wise half
             // ---- output projection backward
             f32x4 dO[8];
             float D[2];        // D = dO . o per head (= sum_t p_t dO.v_t), heads 2h and 2h+1 of the lane's row
@@ -769,6 +789,12 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
             acc_to_x<2>(acc_dx, dy);
             PH_MARK(7)
         }
+        if (MODE == 2 && p.blk == 1) {   // block 1 done: the gradient goes to the row-wise kernel of block 0
+#pragma unroll
+            for (int u = 0; u < 8; ++u) AT4(p.gout, u) = dy[u];
+            first = false;
+            continue;
+        }
         // d(x1) leaves chain-tiled; its column sums (with swish(a2)) feed the second BatchNorm's backward pass
         {
             f32x4 t[8];
@@ -789,20 +815,179 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
         first = false;
     }
     __syncthreads();
-    if (first) zero_floats(part, kTbUnits * 4096);
+    // a workgroup that was handed no tile still owns a partial buffer that the summing launch reads: the units (and, below,
+    // the vector slots) this launch is responsible for
+    if (first && MODE == 0) zero_floats(part, kTbUnits * 4096);
+    if (first && MODE == 2) zero_floats(part + (p.blk * 12 + 8) * 4096, 4 * 4096);
     for (int i = tid; i < kTbVecs * 64; i += blockDim.x) {
         const int slot = i >> 6;
-        if (slot == kSBn2A)
-            atomicAdd(p.bn2_sums + (i & 63), vacc[i]);
-        else if (slot == kSBn2B)
-            atomicAdd(p.bn2_sums + 64 + (i & 63), vacc[i]);
-        else
+        bool mine = true;      // vector slots of this launch (the split form's launches share a workgroup's buffer)
+        if (MODE == 1) mine = slot == kSPoolW || slot == kSPoolB;
+        if (MODE == 2) {
+            const int s_ = slot - p.blk * kSlotsPerBlock;
+            mine = s_ == kSBo || s_ == kSBq || s_ == kSBk || s_ == kSBv;
+        }
+        const bool ends_here = MODE == 0 || (MODE == 2 && p.blk == 0);     // the launch that forms d(x1)
+        if (slot == kSBn2A) {
+            if (ends_here) atomicAdd(p.bn2_sums + (i & 63), vacc[i]);
+        } else if (slot == kSBn2B) {
+            if (ends_here) atomicAdd(p.bn2_sums + 64 + (i & 63), vacc[i]);
+        } else if (mine) {
             part[kTbUnits * 4096 + i] = vacc[i];
+        }
     }
     PH_FLUSH
 #undef AT4
 #undef AT1
 }
+
+// ------------------------------------------------------------------------------------ row-wise half, large batches
+
+// index of the vectors in a workgroup's partial buffer (behind its kRowUnits units)
+enum RowVecSlot { kRG2 = 0, kRB2, kRFb2, kRFb1, kRG1 = kRFb1 + 4, kRB1 };
+static_assert(kRB1 < kRowVecs, "vector slots of the row-wise kernel");
+
+// LayerNorm 2, the feed-forward layers and LayerNorm 1 of ONE TransformerBlock, backward: nothing here looks beyond a
+// row, so a tile is any 128 consecutive rows of the chain-tiled arrays (four 32-row blocks, padding rows of the forward
+// tiling included: their gradients are zero), four wavefronts, two 34 KB transposed images -- and TWO workgroups fit a
+// CU, whose barrier phases then interleave on every SIMD.  Wavefront w owns block w of every 64 x 64 weight-gradient
+// unit over all 128 rows: no exchange between row halves.
+__global__ __launch_bounds__(256, 2) void tb_row_bwd_kernel(TbRowBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* bufA = lds;                               // transposed images [64][kTsRow]
+    float* bufB = bufA + 64 * kTsRow;
+    float* vacc = bufB + 64 * kTsRow;                // [kRowVecs][64] column sums of this workgroup
+    int* tile_slot = reinterpret_cast<int*>(vacc + kRowVecs * 64);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const unsigned seed = p.step[kStepSeed];
+    const int row = wave * 32 + j, row0 = wave * 32;
+    float* lane_a = bufA + 4 * h * kTsRow + row;
+    float* lane_b = bufB + 4 * h * kTsRow + row;
+    float* part = p.part + (size_t)blockIdx.x * kRowPartStride;
+    float* va = vacc + lane;
+    for (int i = tid; i < kRowVecs * 64; i += blockDim.x) vacc[i] = 0.f;
+    __syncthreads();
+    const f32x4* T = p.P;
+    const f32x4* tv = T + kTbVec;
+    const f32x4* TT = p.PT;
+    const int64_t ntiles = (p.nblocks + 3) >> 2;
+    bool first = true;
+    int tile_round = 0;
+#pragma unroll 1
+    for (int64_t tile = next_tile(p.queue, tile_slot, tile_round); tile < ntiles; tile = next_tile(p.queue, tile_slot, tile_round)) {
+        const int64_t rb = (int64_t)__builtin_amdgcn_readfirstlane((int)tile) * 4 + wave;     // this wavefront's 32-row block
+        const bool blk_ok = rb < p.nblocks;                    // the last tile may be short of blocks: those wavefronts carry zeros
+        const int64_t tw = blk_ok ? rb : p.nblocks - 1;
+        // the row's index in the batch (it seeds the dropout mask): forward tile rb / NWf holds S sites from site tile*S on
+        const int64_t ft = rb / p.NWf;
+        const int64_t grow = ft * p.S * p.wlen + (rb - ft * p.NWf) * 32 + j;
+        unsigned ln = (unsigned)lane;
+#define AT4(arr, u) ((arr) + tw * 512 + (u) * 64)[local_index(ln)]
+#define AT1(arr) ((arr) + tw * 64)[local_index(ln)]
+        const f32x2 iv = AT1(p.inv);
+        // ---- LayerNorm 2 backward: dy -> dsum = d(h + f2)
+        f32x4 dsum[8];
+        {
+            f32x4 dy[8], xh[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                dy[u] = AT4(p.din, u);
+                if (!blk_ok) dy[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                xh[u] = keep_load(&AT4(p.xh2, u));
+            }
+            ln_backward<kTsRow>(dy, xh, iv[1], tv + kVLn2G * kVec64, h, dsum, lane_a, lane_b);
+            wave_fence();
+            atomicAdd(va + kRG2 * 64, colsum32_t<kTsRow>(bufA, row0, lane));
+            atomicAdd(va + kRB2 * 64, colsum32_t<kTsRow>(bufB, row0, lane));
+            wave_fence();
+        }
+        f32x4 df2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) df2[u] = dsum[u];
+        dropout_chain(df2, grow, h, seed, p.stream, p.thr, p.scale);
+        f32x4 hx[8];
+        {
+            f32x4 xh[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xh[u] = keep_load(&AT4(p.xh1, u));
+            ln_affine(xh, tv + kVLn1G * kVec64, tv + kVLn1B * kVec64, h, hx);
+        }
+        // ---- feed-forward layers backward; the hidden layer is rebuilt in four 64-wide chunks
+        f32x16 acc_dh[2];
+        x_to_acc(dsum, acc_dh);
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            f32x4 d1[8];
+            {
+                f32x4 g[8];
+                {
+                    f32x16 acc_f[2];
+                    acc_init_bias<2>(acc_f, tv + 9 * kVec64 + 8 * c, h, 32);
+                    gemm_regs<8, 2, 2>(acc_f, T + kTbF1 + (2 * c) * 8 * 64, hx, lane);     // f1_c = h W1[:, chunk] + b1
+                    f32x4 u_[8];
+                    acc_to_x<2>(acc_f, u_);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float a = u_[u][e];
+                            const float sg = fast_rcp(1.0f + __expf(-a));
+                            u_[u][e] = a * sg;                                   // swish(f1_c)
+                            g[u][e] = sg * (1.0f + a * (1.0f - sg));             // swish'(f1_c)
+                        }
+                    chain_store_t<kTsRow>(lane_a, u_);
+                }
+                f32x16 acc_u[2];
+                acc_zero<2>(acc_u);
+                gemm_regs<8, 2, 2>(acc_u, TT + kBtW2T + (2 * c) * 8 * 64, df2, lane);   // d(u_c) = d(f2) W2[chunk, :]^T
+                acc_to_x<2>(acc_u, d1);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) d1[u] *= g[u];                             // d(f1_c)
+            }
+            chain_store_t<kTsRow>(lane_b, df2);
+            if (c == 0) {
+                wave_fence();
+                atomicAdd(va + kRFb2 * 64, colsum32_t<kTsRow>(bufB, row0, lane));
+            }
+            __syncthreads();
+            dw_unit_row(bufA, bufB, part + (4 + c) * 4096, first, lane, wave);         // dW2[chunk, :] += u_c^T d(f2)
+            __syncthreads();   // the images have been read
+            chain_store_t<kTsRow>(lane_a, hx);
+            chain_store_t<kTsRow>(lane_b, d1);
+            wave_fence();
+            atomicAdd(va + (kRFb1 + c) * 64, colsum32_t<kTsRow>(bufB, row0, lane));
+            gemm_k256_chunk(acc_dh, TT + kBtW1T, c, d1, lane);                         // d(h) += d(f1_c) W1[:, chunk]^T
+            __syncthreads();
+            dw_unit_row(bufA, bufB, part + c * 4096, first, lane, wave);               // dW1[:, chunk] += h^T d(f1_c)
+            __syncthreads();
+        }
+        // ---- LayerNorm 1 backward: d(h) -> d(x + attention output), which goes to the attention half
+        {
+            f32x4 dh[8], xh[8];
+            acc_to_x<2>(acc_dh, dh);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xh[u] = keep_load(&AT4(p.xh1, u));
+            ln_backward<kTsRow>(dh, xh, iv[0], tv + kVLn1G * kVec64, h, dsum, lane_a, lane_b);
+            wave_fence();
+            atomicAdd(va + kRG1 * 64, colsum32_t<kTsRow>(bufA, row0, lane));
+            atomicAdd(va + kRB1 * 64, colsum32_t<kTsRow>(bufB, row0, lane));
+            wave_fence();
+        }
+        if (blk_ok) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) AT4(p.dout, u) = dsum[u];
+        }
+        first = false;
+#undef AT4
+#undef AT1
+    }
+    __syncthreads();
+    if (first) zero_floats(part, kRowUnits * 4096);
+    for (int i = tid; i < kRowVecs * 64; i += blockDim.x) part[kRowUnits * 4096 + i] = vacc[i];
+}
+
+static size_t row_lds() { return ((size_t)2 * 64 * kTsRow + kRowVecs * 64 + 64) * sizeof(float); }
 
 // ------------------------------------------------------------------------------------ partial sums -> gradients
 
@@ -810,7 +995,8 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
 // elements each: thread o of a unit is element [block o>>10][register (o>>6)&15][lane o&63]), then the vectors in
 // chunks of 256 floats; grid.y = part group: group y adds parts y, y + gridDim.y, ... and its sum joins the
 // destination through one atomic per element (the destinations start from the step's zeroed gradient buffer).
-__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int nparts, PartUnits ut, PartVecs vt) {
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int nparts, PartUnits ut, PartVecs vt,
+                                                           int stride) {
     const int item = blockIdx.x;
     const float* src;
     float* dst;
@@ -836,20 +1022,20 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
     int pi = blockIdx.y;
     const int stepp = gridDim.y;
     for (; pi + stepp < nparts; pi += 2 * stepp) {
-        a0 += src[(size_t)pi * kTbPartStride];
-        a1 += src[(size_t)(pi + stepp) * kTbPartStride];
+        a0 += src[(size_t)pi * stride];
+        a1 += src[(size_t)(pi + stepp) * stride];
     }
-    if (pi < nparts) a0 += src[(size_t)pi * kTbPartStride];
+    if (pi < nparts) a0 += src[(size_t)pi * stride];
     atomicAdd(dst, a0 + a1);
 }
 
-hipError_t t_reduce_parts(const float* part, int nparts, const PartUnits& u, const PartVecs& v, hipStream_t st) {
+hipError_t t_reduce_parts(const float* part, int nparts, const PartUnits& u, const PartVecs& v, hipStream_t st, int part_stride) {
     int items = u.n * 16;
     for (int i = 0; i < v.n; ++i) items += (v.len[i] + 255) / 256;
     if (items == 0 || nparts == 0) return hipSuccess;
     int groups = (nparts + 15) / 16;
     groups = groups > 8 ? 8 : groups;
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)items, (unsigned)groups), dim3(256), 0, st, part, nparts, u, v);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)items, (unsigned)groups), dim3(256), 0, st, part, nparts, u, v, part_stride);
     return hipGetLastError();
 }
 
@@ -882,15 +1068,116 @@ template <int W>
 static hipError_t launch_bwd(const TbBwdArgs& a, int NW, int grid, hipStream_t st) {
     static bool done[64] = {}, done_small[64] = {};
     if (NW <= 4) {
-        hipError_t e = lds_opt_in(&tb_bwd_kernel<W, 256>, done_small, bwd_lds(4));
+        hipError_t e = lds_opt_in(&tb_bwd_kernel<W, 256, 0>, done_small, bwd_lds(4));
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((tb_bwd_kernel<W, 256>), dim3((unsigned)grid), dim3(64 * NW), bwd_lds(NW), st, a);
+        hipLaunchKernelGGL((tb_bwd_kernel<W, 256, 0>), dim3((unsigned)grid), dim3(64 * NW), bwd_lds(NW), st, a);
         return hipGetLastError();
     }
-    hipError_t e = lds_opt_in(&tb_bwd_kernel<W, 512>, done, bwd_lds(8));
+    hipError_t e = lds_opt_in(&tb_bwd_kernel<W, 512, 0>, done, bwd_lds(8));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((tb_bwd_kernel<W, 512>), dim3((unsigned)grid), dim3(64 * NW), bwd_lds(NW), st, a);
+    hipLaunchKernelGGL((tb_bwd_kernel<W, 512, 0>), dim3((unsigned)grid), dim3(64 * NW), bwd_lds(NW), st, a);
     return hipGetLastError();
+}
+
+// DPTM_TRAIN_SPLIT=0 keeps large batches on the one-launch form (A/B measurements, tests of that form at large tiles)
+static bool split_enabled() {
+    static const bool v = [] {
+        const char* e = std::getenv("DPTM_TRAIN_SPLIT");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+
+// The split form of a large batch: pooling | row-wise half of block 1 | attention half of block 1 | row-wise half of
+// block 0 | attention half of block 0, the gradient travelling through a.dx1 and a.dtmp in turn (the last launch leaves
+// d(x1) in a.dx1), then the sums of the two sets of partial buffers.
+template <int W>
+static hipError_t launch_bwd_split(const TbBwdArgs& a, const TbGrads& g, int grid, hipStream_t st) {
+    static bool done1[64] = {}, done2[64] = {}, done_row[64] = {};
+    hipError_t e = lds_opt_in(&tb_bwd_kernel<W, 512, 1>, done1, bwd_lds(8));
+    if (e == hipSuccess) e = lds_opt_in(&tb_bwd_kernel<W, 512, 2>, done2, bwd_lds(8));
+    if (e == hipSuccess) e = lds_opt_in(&tb_row_bwd_kernel, done_row, row_lds());
+    if (e != hipSuccess) return e;
+    const int NWf = 8;
+    const int64_t nblocks = a.ntiles * NWf, row_tiles = (nblocks + 3) / 4;
+    const int row_grid = (int)(row_tiles < kRowMaxParts ? row_tiles : kRowMaxParts);
+    f32x4_tr* const Da = a.dx1;
+    f32x4_tr* const Db = a.dtmp;
+    auto queue = [&](int k, int64_t tiles, int launch_grid) { return tiles > launch_grid ? a.queues + k : nullptr; };
+    {
+        TbBwdArgs p1 = a;
+        p1.gout = Da;
+        p1.queue = queue(0, a.ntiles, grid);
+        hipLaunchKernelGGL((tb_bwd_kernel<W, 512, 1>), dim3((unsigned)grid), dim3(512), bwd_lds(8), st, p1);
+    }
+    for (int blk = 1; blk >= 0; --blk) {
+        TbRowBwdArgs r;
+        r.P = a.P + kOffTb + blk * kTbSize;
+        r.PT = a.PT + blk * kBtSize;
+        r.xh1 = a.sv[blk].xh1;
+        r.xh2 = a.sv[blk].xh2;
+        r.inv = a.sv[blk].inv;
+        r.din = Da;
+        r.dout = Db;
+        r.part = a.row_part + (size_t)blk * kRowMaxParts * kRowPartStride;
+        r.queue = queue(blk == 1 ? 1 : 3, row_tiles, row_grid);
+        r.n_sites = a.n_sites;
+        r.S = a.S;
+        r.wlen = W;
+        r.NWf = NWf;
+        r.nblocks = nblocks;
+        r.step = a.step;
+        r.stream = a.stream_base + 2 * blk + 1;
+        r.thr = a.thr;
+        r.scale = a.scale;
+        hipLaunchKernelGGL(tb_row_bwd_kernel, dim3((unsigned)row_grid), dim3(256), row_lds(), st, r);
+        TbBwdArgs p2 = a;
+        p2.blk = blk;
+        p2.gin = Db;
+        p2.gout = Da;          // (block 0 writes a.dx1 itself, which is the same array)
+        p2.queue = queue(blk == 1 ? 2 : 4, a.ntiles, grid);
+        hipLaunchKernelGGL((tb_bwd_kernel<W, 512, 2>), dim3((unsigned)grid), dim3(512), bwd_lds(8), st, p2);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // sums: the site-aware launches' buffers (4 units per block, their bias vectors, the pooling) ...
+    {
+        PartUnits ut;
+        PartVecs vt;
+        for (int b = 0; b < 2; ++b) {
+            float* sq[4] = {g.wo[b], g.wq[b], g.wk[b], g.wv[b]};
+            float* vb[4] = {g.bo[b], g.bq[b], g.bk[b], g.bv[b]};
+            const int vs[4] = {kSBo, kSBq, kSBk, kSBv};
+            for (int i = 0; i < 4; ++i) {
+                ut.dst[ut.n] = sq[i]; ut.off[ut.n] = (b * 12 + 8 + i) * 4096; ut.ld[ut.n] = 64; ut.rows[ut.n] = 64; ++ut.n;
+                vt.dst[vt.n] = vb[i]; vt.off[vt.n] = kTbUnits * 4096 + (b * kSlotsPerBlock + vs[i]) * 64; vt.len[vt.n] = 64; ++vt.n;
+            }
+        }
+        vt.dst[vt.n] = g.poolw; vt.off[vt.n] = kTbUnits * 4096 + kSPoolW * 64; vt.len[vt.n] = 64; ++vt.n;
+        vt.dst[vt.n] = g.poolb; vt.off[vt.n] = kTbUnits * 4096 + kSPoolB * 64; vt.len[vt.n] = 1; ++vt.n;
+        e = t_reduce_parts(a.part, grid, ut, vt, st, kTbPartStride);
+        if (e != hipSuccess) return e;
+    }
+    // ... and the row-wise launches' (8 units and 9 vectors per block)
+    for (int b = 0; b < 2; ++b) {
+        PartUnits ut;
+        PartVecs vt;
+        for (int c = 0; c < 4; ++c) {
+            ut.dst[ut.n] = g.w1[b] + 64 * c; ut.off[ut.n] = c * 4096; ut.ld[ut.n] = 256; ut.rows[ut.n] = 64; ++ut.n;
+        }
+        for (int c = 0; c < 4; ++c) {
+            ut.dst[ut.n] = g.w2[b] + 64 * c * 64; ut.off[ut.n] = (4 + c) * 4096; ut.ld[ut.n] = 64; ut.rows[ut.n] = 64; ++ut.n;
+        }
+        auto vec = [&](float* dst, int slot) {
+            vt.dst[vt.n] = dst; vt.off[vt.n] = kRowUnits * 4096 + slot * 64; vt.len[vt.n] = 64; ++vt.n;
+        };
+        vec(g.ln2g[b], kRG2); vec(g.ln2b[b], kRB2); vec(g.b2[b], kRFb2);
+        for (int c = 0; c < 4; ++c) vec(g.b1[b] + 64 * c, kRFb1 + c);
+        vec(g.ln1g[b], kRG1); vec(g.ln1b[b], kRB1);
+        e = t_reduce_parts(a.row_part + (size_t)b * kRowMaxParts * kRowPartStride, row_grid, ut, vt, st, kRowPartStride);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t t_tb_bwd(const TbBwdArgs& a, const TbGrads& g, int wlen, int NW, PartPlan* plan, hipStream_t st) {
@@ -898,6 +1185,16 @@ hipError_t t_tb_bwd(const TbBwdArgs& a, const TbGrads& g, int wlen, int NW, Part
     if (!tile_ok(wlen, a.S, NW, a.n_sites, a.ntiles)) return hipErrorInvalidValue;
     const int grid = (int)(a.ntiles < kTbMaxParts ? a.ntiles : kTbMaxParts);
     hipError_t e;
+    if (NW == 8 && !part_sums_deferred(a.ntiles) && a.row_part && a.dtmp && a.queues && split_enabled()) {
+        switch (wlen) {
+            case 21: e = launch_bwd_split<21>(a, g, grid, st); break;
+            case 33: e = launch_bwd_split<33>(a, g, grid, st); break;
+            default: e = launch_bwd_split<51>(a, g, grid, st); break;
+        }
+        plan->units.n = 0;
+        plan->vecs.n = 0;
+        return e;
+    }
     switch (wlen) {
         case 21: e = launch_bwd<21>(a, NW, grid, st); break;
         case 33: e = launch_bwd<33>(a, NW, grid, st); break;

@@ -222,6 +222,36 @@ struct TbBwdArgs {
     const unsigned* step;
     unsigned stream_base, thr;
     float scale;
+    // ---- the split form of large batches (t_tb_bwd decides): the row-wise half of every block -- LayerNorm 2, feed-forward
+    // layers, LayerNorm 1 -- runs as tb_row_bwd_kernel, this kernel does the pooling (part 1) or the attention half of
+    // block `blk` (part 2), and the gradient travels between the launches through two chain-tiled arrays
+    int blk;               // part 2: the block in hand
+    const f32x4_tr* gin;   // part 2: d(x + attention output) of the block, from the row-wise kernel
+    f32x4_tr* gout;        // part 1, part 2 with blk = 1: gradient w.r.t. the output of the block below
+    f32x4_tr* dtmp;        // second hand-over array (free while the TransformerBlocks go backward)
+    float* row_part;       // [kRowMaxParts][kRowPartStride] partial gradients of the row-wise launches
+    unsigned* queues;      // five tile counters for the split form's launches, zero when the step starts
+};
+// Row-wise half of one TransformerBlock's backward pass (no site structure: tiles of any 128 rows).
+constexpr int kRowUnits = 8;       // dW1 chunks 0..3, dW2 chunks 0..3
+constexpr int kRowVecs = 10;       // LayerNorm 2 gamma / beta, b2, b1 chunks 0..3, LayerNorm 1 gamma / beta, (spare)
+constexpr int kRowPartStride = kRowUnits * 4096 + kRowVecs * 64;      // 33,408 floats, a multiple of 64
+constexpr int kRowMaxParts = 512;
+struct TbRowBwdArgs {
+    const f32x4_tr* P;     // packed image of the block (p.P + kOffTb + blk * kTbSize)
+    const f32x4_tr* PT;    // transposed images of the block (p.PT + blk * kBtSize)
+    const f32x4_tr *xh1, *xh2;
+    const f32x2_tr* inv;
+    const f32x4_tr* din;   // gradient w.r.t. the block's output
+    f32x4_tr* dout;        // d(x + attention output): input of the attention half
+    float* part;           // [grid][kRowPartStride]
+    unsigned* queue;
+    int64_t n_sites;       // validity of a row: the forward tiling (S sites of wlen rows in NWf wavefronts per tile)
+    int S, wlen, NWf;
+    int64_t nblocks;       // 32-row blocks of the chain-tiled arrays (forward tiles x NWf)
+    const unsigned* step;
+    unsigned stream, thr;  // dropout behind the feed-forward layers
+    float scale;
 };
 // gradient tensors (raw layouts) that the partial sums are added to
 struct TbGrads {
@@ -261,7 +291,8 @@ struct PartPlan {
     PartVecs vecs;
 };
 inline bool part_sums_deferred(int64_t ntiles) { return ntiles <= kTbMaxParts; }
-hipError_t t_reduce_parts(const float* part, int nparts, const PartUnits& u, const PartVecs& v, hipStream_t st);
+hipError_t t_reduce_parts(const float* part, int nparts, const PartUnits& u, const PartVecs& v, hipStream_t st,
+                          int part_stride = kTbPartStride);
 
 // ---- fused embedding + residual convolution block (dptm_train_conv.hip); transposed images of the convolution
 // kernels follow the two blocks' images in PT: shortcut^T, conv3a taps^T, conv3b taps^T (packed 64 x 64 each)

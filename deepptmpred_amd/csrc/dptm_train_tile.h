@@ -167,16 +167,23 @@ __device__ __forceinline__ void ln_affine(const f32x4 (&xh)[8], const f32x4* __r
 // ---- transposed LDS images [feature][row] (row stride kTs): the layout the weight-gradient unit reads with
 // 16-byte loads.  A lane stores its 32 features as single floats (consecutive lanes = consecutive rows =
 // consecutive addresses).  lane_base = image + 4*h*kTs + row of the lane.
+template <int TS = kTs>
 __device__ __forceinline__ void chain_store_t(float* lane_base, const f32x4 (&x)[8]) {
+    // the 32 addresses are formed from the base here, at the stores: hoisted out of a loop that calls this several
+    // times they would be 15 more live registers each
+    unsigned zero = 0;
+    DPTM_LOCAL_INDEX(zero);
+    lane_base += zero;
 #pragma unroll
     for (int u = 0; u < 8; ++u)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) lane_base[(8 * u + e) * kTs] = x[u][e];
+        for (int e = 0; e < 4; ++e) lane_base[(8 * u + e) * TS] = x[u][e];
 }
 
 // sum over rows row0 .. row0+31 (row0 a multiple of 32) of feature `lane` of a transposed image
+template <int TS = kTs>
 __device__ __forceinline__ float colsum32_t(const float* imgT, int row0, int lane) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(imgT + lane * kTs + row0);
+    const f32x4* p = reinterpret_cast<const f32x4*>(imgT + lane * TS + row0);
     f32x4 s = p[0];
 #pragma unroll
     for (int i = 1; i < 8; ++i) s += p[i];
@@ -187,6 +194,7 @@ __device__ __forceinline__ float colsum32_t(const float* imgT, int row0, int lan
 // The parameter gradients need column sums over rows: dy * xhat goes to the lane's row of one transposed image
 // (lane_a, see chain_store_t) and dy to a second one (the wavefront's own 32 rows of two idle images), from where
 // colsum32_t takes them.
+template <int TS = kTs>
 __device__ __forceinline__ void ln_backward(const f32x4 (&dy)[8], const f32x4 (&xh)[8], float inv, const f32x4* __restrict__ g,
                                             int h, f32x4 (&dsum)[8], float* lane_a, float* lane_b) {
     DPTM_LOCAL_INDEX(h);
@@ -202,8 +210,8 @@ __device__ __forceinline__ void ln_backward(const f32x4 (&dy)[8], const f32x4 (&
             s2 = fmaf(dsum[u][e], xh[u][e], s2);
         }
     }
-    chain_store_t(lane_a, t);
-    chain_store_t(lane_b, dy);
+    chain_store_t<TS>(lane_a, t);
+    chain_store_t<TS>(lane_b, dy);
     s1 = xhalf_sum(s1) * (1.0f / 64.0f);
     s2 = xhalf_sum(s2) * (1.0f / 64.0f);
 #pragma unroll
@@ -343,6 +351,41 @@ __device__ __forceinline__ void dw_unit_t(const float* imgXT, const float* imgYT
         }
     }
     if (NW != 8) DW_SYNC();
+}
+
+// The unit of the row-wise backward kernel: four wavefronts, 128 rows, transposed images of row stride kTsRow.  Wavefront
+// w contracts block w over all 128 rows, so there is no exchange between row halves and no barrier inside; the caller
+// puts one barrier between writing the images and this call and one before it overwrites them.
+constexpr int kTsRow = 132;     // 128 rows + 4
+__device__ __forceinline__ void dw_unit_row(const float* imgXT, const float* imgYT, float* __restrict__ part_u, bool first,
+                                            int lane, int wave) {
+    const int hh = lane >> 5, i = lane & 31;
+    const int b = wave;
+    const float* ap = imgXT + (32 * (b >> 1) + i) * kTsRow + 4 * hh;
+    const float* bp = imgYT + (32 * (b & 1) + i) * kTsRow + 4 * hh;
+    float* dst = part_u + b * 1024 + lane;
+    f32x16 acc, prev;
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) acc[rg] = prev[rg] = 0.f;
+    if (!first) {
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) prev[rg] = dst[rg * 64];
+    }
+    f32x4 ca = *reinterpret_cast<const f32x4*>(ap), cb = *reinterpret_cast<const f32x4*>(bp);
+#pragma unroll 2
+    for (int g = 0; g < 16; ++g) {
+        f32x4 na = ca, nb = cb;
+        if (g + 1 < 16) {
+            na = *reinterpret_cast<const f32x4*>(ap + 8 * (g + 1));
+            nb = *reinterpret_cast<const f32x4*>(bp + 8 * (g + 1));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mfma(acc, ca[e], cb[e]);
+        ca = na;
+        cb = nb;
+    }
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) dst[rg * 64] = acc[rg] + prev[rg];
 }
 
 // scale | shift of a BatchNormalization in training mode from the column sums of its input (keras epsilon 1e-3,

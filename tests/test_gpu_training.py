@@ -44,11 +44,11 @@ def _compare_grads(got_blob, want, label):
 
 # 48 sites: the small-batch kernels; 230 sites (4,830 to 11,730 window rows): the LDS-staged matrix products that
 # large row stacks take, with a ragged last row tile
-# The fused TransformerBlock kernels tile a branch by whole sites in 1, 2, 4 or 8 wavefronts, the tile growing with the
-# batch: 600 sites take the two- and four-wavefront tiles (and more tiles than workgroups, so partial gradients are
-# accumulated over several tiles), 2,411 sites the eight-wavefront tiles with a ragged last tile.
-# 100 sites: the four-row-tile instance of the small-batch per-site kernels (65..128 sites); 4,100 sites: the per-site
-# layers' LDS-staged products (row stacks of 4,096 and more) and more eight-wavefront tiles than workgroups.
+# The TransformerBlock kernels tile a branch by whole sites in four or eight wavefronts: 100 and 230 sites take the
+# four-wavefront tiles (100 also the four-row-tile instance of the small-batch per-site kernels, 65..128 sites), 600
+# sites the eight-wavefront tiles with fewer tiles than workgroups, 2,411 sites a ragged last tile and more tiles than
+# workgroups (partial gradients accumulated over several tiles), 4,100 sites the per-site layers' LDS-staged
+# products (row stacks of 4,096 and more).
 @pytest.mark.parametrize("rates,n", [((0.0, 0.0, 0.0, 0.0), 48), ((1e-4, 0.3, 0.1, 0.3), 48), ((1e-4, 0.3, 0.1, 0.3), 100),
                                      ((1e-4, 0.3, 0.1, 0.3), 230), ((1e-4, 0.3, 0.1, 0.3), 600), ((1e-4, 0.3, 0.1, 0.3), 2411),
                                      ((1e-4, 0.3, 0.1, 0.3), 4100)])
@@ -78,9 +78,9 @@ def test_gradients_match_autograd(rates, n):
 
 
 # batch sizes on both sides of every switch the step makes: 1 row tile / 2 / 4 of the per-site kernels (32|33, 64|65),
-# one-site four-wavefront tiles / one- and two-wavefront tiles (85|86), per-site kernels / layer-wise products (128|129),
-# one-site tiles / larger tiles (191|192); 7 sites: a batch far below one row tile (with 2 sites BatchNorm over two rows amplifies fp32 rounding beyond the bound)
-@pytest.mark.parametrize("n", [7, 33, 65, 85, 86, 129, 192])
+# one-site four-wavefront tiles / whole sites in four wavefronts (85|86), per-site kernels / layer-wise products (128|129),
+# four- / eight-wavefront tiles (231|232); 7 sites: a batch far below one row tile (with 2 sites BatchNorm over two rows amplifies fp32 rounding beyond the bound)
+@pytest.mark.parametrize("n", [7, 33, 65, 85, 86, 129, 231, 232])
 def test_gradients_at_regime_boundaries(n):
     import torch
     rates = (1e-4, 0.3, 0.1, 0.3)
