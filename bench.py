@@ -55,9 +55,9 @@ PEAK_MFMA = {"f32": PEAK_F32_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS, "f16": 
              "bf16": PEAK_F16_MFMA_TFLOPS}
 KERNEL_NAME = {"f32": "branch_kernel<51>", "f16x3": "branch_kernel_h<51,f16x3>", "f16": "branch_kernel_h<51,f16>",
                "bf16": "branch_kernel_h<51,bf16>"}
-TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r2_pmc_traffic.json", "r1_pmc_traffic.json")]
-ISSUE_FILES = [os.path.join(ROOT, "profiles", "r2_pmc_summary.json")]
-TRAIN_TRAFFIC_FILES = [os.path.join(ROOT, "profiles", "r2_train_pmc_traffic.json")]
+TRAFFIC_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")]
+ISSUE_FILES = [os.path.join(ROOT, "profiles", f) for f in ("r3_pmc_summary.json", "r2_pmc_summary.json")]
+TRAIN_TRAFFIC_FILES = [os.path.join(ROOT, "profiles", "r3_train_pmc_traffic.json")]
 ASSEMBLE_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r2_pmc_assemble.json")
 PEAK_HBM_GBS = 8000.0
 N_SIMD = 1024                        # 256 CUs x 4 SIMDs
@@ -359,10 +359,12 @@ def measure_train(R: Ranks, batch: int, steps: int, warmup: int) -> dict:
     backend.close()
     value = world * batch * steps / elapsed
     tf = value / world * 3 * FLOPS_PER_SITE / 1e12
-    # dominant kernel: both TransformerBlocks + pooling backward of the W=51 branch, one launch per step
+    # dominant piece: both TransformerBlocks + pooling backward of the W=51 branch -- one launch per step at small
+    # batches, five at large ones (pooling, then the row-wise and the attention half of each block); the library's
+    # own clock around them ("tb_bwd51") is the duration, the committed --pmc passes sum the same launches
     bwd_s = kernel_ms["tb_bwd51"] * 1e-3
     bwd_tf = batch * 2 * TB_FWD_FLOPS[51] / bwd_s / 1e12 if bwd_s > 0 else 0.0
-    traffic, traffic_file = None, None
+    traffic, traffic_file, launches = None, None, None
     for path in TRAIN_TRAFFIC_FILES:
         try:
             with open(path) as f:
@@ -371,11 +373,12 @@ def measure_train(R: Ranks, batch: int, steps: int, warmup: int) -> dict:
             continue
         if rec:
             traffic, traffic_file = rec.get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT)
+            launches = rec.get("launches_per_pass")
             break
-    roofline = {"bound": "mfma", "kernel": "tb_bwd_kernel<51>", "achieved": bwd_tf, "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": bwd_tf / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+    roofline = {"bound": "mfma", "kernel": "tb_bwd_kernel<51> (+ tb_row_bwd_kernel at large batches)", "achieved": bwd_tf,
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": bwd_tf / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                 "traffic_source": f"{traffic_file} (offline rocprofv3 --pmc passes of bench.py --train)" if traffic_file else None,
-                "avg_launch_ms": kernel_ms["tb_bwd51"], "sites_per_launch": batch,
+                "avg_launch_ms": kernel_ms["tb_bwd51"], "launches_per_pass": launches, "sites_per_launch": batch,
                 "flops_per_site": 2 * TB_FWD_FLOPS[51]}
     return {"batch_per_gpu": batch, "steps": steps, "ms_per_step": elapsed / steps * 1e3, "sites_per_s": value,
             "tflops_per_gpu": tf, "frac_of_f32_mfma_peak": tf / PEAK_F32_MFMA_TFLOPS, "roofline": roofline,

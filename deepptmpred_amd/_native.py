@@ -33,7 +33,7 @@ EXPORTS = (
     "dptm_trainer_grad_buffer", "dptm_trainer_param_floats", "dptm_trainer_apply",
     "dptm_trainer_get_weights", "dptm_trainer_get_grads", "dptm_trainer_get_proba",
     "dptm_trainer_get_optimizer_state", "dptm_trainer_set_optimizer_state",
-    "dptm_trainer_profile_begin", "dptm_trainer_profile_end", "dptm_trainer_loss_buffer", "dptm_trainer_stream",
+    "dptm_trainer_profile_begin", "dptm_trainer_profile_end", "dptm_trainer_loss_buffer", "dptm_trainer_proba_buffer", "dptm_trainer_stream",
     "dptm_trainer_stage_loss", "dptm_trainer_lanes",
     "dptm_trainer_last_error", "dptm_trainer_set_allreduce", "dptm_sasa", "dptm_sasa_last_error",
 )
@@ -182,6 +182,8 @@ def load_library() -> C.CDLL:
     lib.dptm_trainer_set_optimizer_state.argtypes = [vp, f32p, f32p, i64]
     lib.dptm_trainer_loss_buffer.restype = C.c_int
     lib.dptm_trainer_loss_buffer.argtypes = [vp, C.POINTER(vp)]
+    lib.dptm_trainer_proba_buffer.restype = C.c_int
+    lib.dptm_trainer_proba_buffer.argtypes = [vp, C.POINTER(vp)]
     lib.dptm_trainer_stage_loss.restype = C.c_int
     lib.dptm_trainer_stage_loss.argtypes = [vp, C.POINTER(i64), vp]
     lib.dptm_trainer_lanes.restype = C.c_int
@@ -466,6 +468,13 @@ class Trainer:
         """Device address of the step's loss (one float32, written by forward_backward in stream order)."""
         p = C.c_void_p()
         _check_t(self._lib, self._lib.dptm_trainer_loss_buffer(self._h, C.byref(p)), "dptm_trainer_loss_buffer")
+        return int(p.value)
+
+    def proba_buffer(self) -> int:
+        """Device address of the step's class probabilities ([n][2] float32, the training-mode outputs that
+        forward_backward writes in stream order)."""
+        p = C.c_void_p()
+        _check_t(self._lib, self._lib.dptm_trainer_proba_buffer(self._h, C.byref(p)), "dptm_trainer_proba_buffer")
         return int(p.value)
 
     def stage_loss(self, stream=0) -> int:

@@ -784,6 +784,14 @@ int dptm_trainer_loss_buffer(dptm_trainer* t, float** dev_ptr) try {
     return on_texception("dptm_trainer_loss_buffer");
 }
 
+int dptm_trainer_proba_buffer(dptm_trainer* t, float** dev_ptr) try {
+    if (!t || !dev_ptr) return tfail(DPTM_EINVAL, "dptm_trainer_proba_buffer: NULL argument");
+    *dev_ptr = t->proba;
+    return DPTM_OK;
+} catch (...) {
+    return on_texception("dptm_trainer_proba_buffer");
+}
+
 int dptm_trainer_stage_loss(dptm_trainer* t, int64_t* slot, void* stream) try {
     if (!t || !slot) return tfail(DPTM_EINVAL, "dptm_trainer_stage_loss: NULL argument");
     T_TRY(hipSetDevice(t->device));

@@ -240,7 +240,10 @@ class Model:
                 h1 = trainer.fit(x, y_labels, batch_size, 1, shuffle, lambda _e, _lr, _v=lr: _v, seed=epoch, verbose=0,
                                  keep_resident=True)
                 self._dirty = True
-                logs = {"loss": h1["loss"][0], "lr": lr}
+                logs = {"loss": h1["loss"][0]}
+                for k in ("accuracy", "auc"):           # the compiled metrics of trainer.py:308, over the epoch's batches
+                    if k in h1:
+                        logs[k] = h1[k][0]
                 if validation_data is not None:
                     vx, vy = validation_data
                     vl = labels_from_targets(vy)
@@ -250,6 +253,7 @@ class Model:
                     logs["val_loss"] = balanced_bce(p, vl) + reg
                     logs["val_accuracy"] = float(np.mean(np.argmax(p, axis=1) == vl))
                     logs["val_auc"] = roc_auc(vl, p[:, 1])
+                logs["lr"] = lr
                 for k, v in logs.items():
                     hist.setdefault(k, []).append(v)
                 if verbose:

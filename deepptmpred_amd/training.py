@@ -152,6 +152,7 @@ class NativeBackend:
         self._data = data
         self._data_key = key
         self._loss_view = self._wrap(self.trainer.loss_buffer(), 1)
+        self._proba_view = self._wrap(self.trainer.proba_buffer(), 2 * self.trainer.max_batch)
         return True
 
     def drop_dataset(self) -> None:
@@ -172,9 +173,10 @@ class NativeBackend:
         return self._stage
 
     def forward_backward_resident(self, idx_dev, n_global: int, n_pos_global: int, seed: int, rates: DropoutRates,
-                                  l2: float, l2_scale: float, loss_out) -> None:
+                                  l2: float, l2_scale: float, loss_out, proba_out=None) -> None:
         """One step on the rows ``idx_dev`` (device int64 tensor) of the resident data set; the step's loss is copied
-        to the one-element device tensor ``loss_out`` (``None``: the caller takes it from ``allreduce_grads``).
+        to the one-element device tensor ``loss_out`` (``None``: the caller takes it from ``allreduce_grads``) and
+        its class probabilities -- the training-mode outputs -- to ``proba_out`` (2 floats per row).
         Nothing here waits for the GPU."""
         t = self.torch
         d = self._staging()
@@ -191,6 +193,19 @@ class NativeBackend:
                                           d[4].data_ptr(), d[5].data_ptr(), n, o, False, self.stream.cuda_stream)
             if loss_out is not None:
                 loss_out.copy_(self._loss_view, non_blocking=True)
+            if proba_out is not None:
+                proba_out.copy_(self._proba_view[:2 * n], non_blocking=True)
+
+    def allreduce_floats(self, dev_tensor, group=None) -> None:
+        """Sum of a device tensor over the replicas, in the order of the backend's stream."""
+        import torch.distributed as dist
+        with self.torch.cuda.stream(self.stream):
+            if dist.get_backend(group) == "nccl":
+                dist.all_reduce(dev_tensor, op=dist.ReduceOp.SUM, group=group)
+            else:
+                h = dev_tensor.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                dev_tensor.copy_(h)
 
     def enable_sync_batchnorm(self, group=None) -> None:
         """Every BatchNorm then normalises with the statistics of the GLOBAL batch: its column sums are
@@ -342,6 +357,7 @@ class DataParallelTrainer:
                     torch = self.backend.torch
                     starts = list(range(0, n, batch_size))
                     losses_dev = self.backend.new_loss_buffer(len(starts))
+                    proba_dev = self.backend.new_loss_buffer(2 * n)     # row i: the outputs for sample order[i]
                     with torch.cuda.stream(self.backend.stream):
                         order_dev = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int64)).to(self.backend.device)
                     for k, s in enumerate(starts):
@@ -352,21 +368,37 @@ class DataParallelTrainer:
                         own = losses_dev[k:k + 1]
                         self.backend.forward_backward_resident(order_dev[s + lo:s + hi], len(idx), int(labels[idx].sum()),
                                                                self.steps * 1000003 + rank, self.rates, self.l2, 1.0 / world,
-                                                               own if world == 1 else None)
+                                                               own if world == 1 else None,
+                                                               proba_dev[2 * (s + lo):2 * (s + hi)])
                         if world > 1:
                             self.backend.allreduce_grads(self.group, loss_out=own)
                         self.backend.apply(lr, self.optimizer.weight_decay, 1.0 / world)
                         self.steps += 1
+                    if world > 1:          # every replica filled the rows of its shards: one sum per epoch joins them
+                        self.backend.allreduce_floats(proba_dev, self.group)
                     hist["loss"].append(float(self.backend.read_floats(losses_dev).astype(np.float64).mean()))
+                    proba = self.backend.read_floats(proba_dev).reshape(n, 2)
                 else:
                     losses = []
+                    can_read = world == 1 and hasattr(getattr(self.backend, "trainer", None), "get_proba")
+                    proba = np.zeros((n, 2), np.float32) if can_read else None
                     for s in range(0, n, batch_size):
                         idx = order[s:s + batch_size]
                         losses.append(self.train_on_batch([np.asarray(a)[idx] for a in x], labels[idx], lr))
+                        if can_read:
+                            proba[s:s + len(idx)] = self.backend.trainer.get_proba(len(idx))
                     hist["loss"].append(float(np.mean(losses)))
+                if proba is not None:
+                    # what Keras logs as `accuracy` and `auc` (trainer.py:308): accumulated over the epoch's batches
+                    # from the training-mode outputs, weights changing from batch to batch
+                    from .callbacks import roc_auc
+                    yl = labels[order]
+                    hist.setdefault("accuracy", []).append(float(np.mean(np.argmax(proba, axis=1) == yl)))
+                    hist.setdefault("auc", []).append(roc_auc(yl, proba[:, 1]))
                 hist["lr"].append(lr)
                 if verbose:
-                    print(f"epoch {ep + 1}/{epochs} - loss {hist['loss'][-1]:.4f} - lr {lr:.2e}")
+                    extra = "".join(f" - {k} {hist[k][-1]:.4f}" for k in ("accuracy", "auc") if k in hist)
+                    print(f"epoch {ep + 1}/{epochs} - loss {hist['loss'][-1]:.4f}{extra} - lr {lr:.2e}")
         except BaseException:
             if resident:                        # never leave a device copy behind that a later call could mistake for its data
                 self.backend.drop_dataset()

@@ -318,6 +318,12 @@ int dptm_trainer_set_optimizer_state(dptm_trainer* t, const float* m_host, const
  * step and reads the copies once per epoch need not wait for the GPU at every step, as Keras' model.fit does not
  * (pred/train_PTM/trainer.py:332-339: the per-batch losses only surface as the epoch's mean). */
 int dptm_trainer_loss_buffer(dptm_trainer* t, float** dev_ptr);
+/* Device address of the step's class probabilities: [n][2] floats (n = the step's sites; room for max_batch) that
+ * dptm_trainer_forward_backward writes in stream order -- the training-mode outputs (dropout on, batch statistics)
+ * from which Keras accumulates the `accuracy` and `auc` it logs per epoch (pred/train_PTM/trainer.py:308: compile
+ * with metrics=['accuracy', AUC(name='auc')]).  A loop copies them device-to-device after each step and reads the
+ * copies once per epoch; dptm_trainer_get_proba is the host copy that waits. */
+int dptm_trainer_proba_buffer(dptm_trainer* t, float** dev_ptr);
 
 /* Data-parallel jobs: copies the step's loss (dptm_trainer_loss_buffer) into a float of the gradient buffer that no
  * parameter uses -- the last float of the buffer, padding behind the head bias -- in stream order, and returns that

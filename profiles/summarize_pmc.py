@@ -3,7 +3,7 @@
   profiles/<tag>_kernel_stats.csv, <tag>_bench_under_rocprof.json     kernel trace of the default bench
   profiles/<tag>_pmc_traffic.json, <tag>_pmc_summary.json             W=51 scoring kernel per precision
   profiles/<tag>_train_b<batch>_serial_kernel_stats.csv, <tag>_train_b<batch>_bench_under_rocprof.json
-  profiles/<tag>_train_pmc_traffic.json, <tag>_train_pmc_summary.json  tb_bwd_kernel<51> of the training step
+  profiles/<tag>_train_pmc_traffic.json, <tag>_train_pmc_summary.json  W=51 backward pass of the training step
   profiles/<tag>_probe_insts.json                                      what SQ_INSTS_VALU counts (coexec_probe)
   profiles/<tag>_pmc_assemble.json                                     HBM-side traffic of the window-assembly kernel
   profiles/<tag>_issue_cost.txt, <tag>_pmc_classes.json                issue cost per instruction class (issue_cost_probe)
@@ -31,15 +31,22 @@ dst = os.path.join(root, "profiles")
 
 
 def per_kernel(pattern, want):
-    """{kernel family: {counter: [values per dispatch]}} from the newest counter_collection csv of a pass"""
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    """{kernel family: {counter: [value per dispatch, in dispatch order]}} from the newest counter_collection csv of a
+    pass; "_dur_ns" holds the dispatches' durations in the same order"""
+    rows = collections.defaultdict(lambda: collections.defaultdict(dict))
     files = sorted(glob.glob(os.path.join(src, pattern, "*", "*counter_collection.csv")), key=os.path.getmtime)
     for f in files[-1:]:                 # the most recent pass only (gpurun merges new files next to old ones)
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0]
             if want(name):
-                agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
-                agg[name]["_dur_ns"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                d = rows[name][int(r["Dispatch_Id"])]
+                d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                d["_dur_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for name, by_id in rows.items():
+        for i in sorted(by_id):
+            for c, v in by_id[i].items():
+                agg[name][c].append(v)
     return agg
 
 
@@ -124,7 +131,39 @@ if os.path.exists(tb) and bench_line("trace_bench.json"):
     shutil.copy(tb, os.path.join(dst, tag + "_bench_under_rocprof.json"))
 
 # ---------------------------------------------------------------- training step
+# The backward pass of the W=51 branch's TransformerBlocks + pooling is ONE launch at small batches
+# (tb_bwd_kernel<51, 256, 0>) and FIVE at large ones: tb_bwd_kernel<51, 512, 1> (pooling), then per block
+# tb_row_bwd_kernel (row-wise half; one kernel for all window sizes -- the W=51 launches are the longest third of its
+# launches) and tb_bwd_kernel<51, 512, 2> (attention half).  Counters and durations are summed over those launches:
+# "per launch" below means per backward pass of the branch.
 is_train = lambda n: "tb_" in n or "conv_" in n
+
+
+def bwd51(agg):
+    """(label, {counter: [per-pass value]}, launches per pass) of the W=51 backward pass"""
+    parts = []
+    for k, v in agg.items():
+        if "tb_bwd_kernel<51" in k:
+            parts.append((k, v, None))
+        elif "tb_row_bwd_kernel" in k:
+            parts.append((k, v, "top_third"))
+    if not parts:
+        return None, None, 0
+    passes = min(len(v["_dur_ns"]) for k, v, sel in parts if sel is None and (k.endswith(", 1>") or k.endswith(", 0>")))
+    out = collections.defaultdict(float)
+    launches = 0
+    for k, v, sel in parts:
+        n = len(v["_dur_ns"])
+        keep = range(n)
+        if sel == "top_third":
+            keep = sorted(range(n), key=lambda i: -v["_dur_ns"][i])[:n // 3]
+        launches += len(keep)
+        for c, vals in v.items():
+            out[c] += sum(vals[i] for i in keep) / passes
+    label = " + ".join(sorted(k for k, _, _ in parts))
+    return label, {c: [x] for c, x in out.items()}, launches // passes
+
+
 ttraffic, tsummary = {}, {}
 for batch in (8192, 64):
     b = "b%d" % batch
@@ -132,16 +171,17 @@ for batch in (8192, 64):
         shutil.copy(f, os.path.join(dst, "%s_train_%s_serial_kernel_stats.csv" % (tag, b)))
     if bench_line("train_trace_%s.json" % b):
         shutil.copy(os.path.join(src, "train_trace_%s.json" % b), os.path.join(dst, "%s_train_%s_bench_under_rocprof.json" % (tag, b)))
-    kf, f = pick(per_kernel("train_fetch_" + b, is_train), "tb_bwd_kernel", "<51")
-    kw, w = pick(per_kernel("train_write_" + b, is_train), "tb_bwd_kernel", "<51")
-    km, m = pick(per_kernel("train_mfma_" + b, is_train), "tb_bwd_kernel", "<51")
+    kf, f, nl = bwd51(per_kernel("train_fetch_" + b, is_train))
+    kw, w, _ = bwd51(per_kernel("train_write_" + b, is_train))
+    km, m, _ = bwd51(per_kernel("train_mfma_" + b, is_train))
     if f and w:
         fetch_kib, write_kib = mean(f["FETCH_SIZE"]), mean(w["WRITE_SIZE"])
-        ttraffic["batch%d" % batch] = {"kernel": kf, "launches": len(f["FETCH_SIZE"]), "sites_per_launch": batch,
+        ttraffic["batch%d" % batch] = {"kernel": kf, "launches_per_pass": nl, "sites_per_launch": batch,
                                        "FETCH_SIZE_KiB_per_launch": fetch_kib, "WRITE_SIZE_KiB_per_launch": write_kib,
                                        "traffic_bytes_per_launch": (2 * fetch_kib + write_kib) * 1024}
     if m:
         tsummary["batch%d" % batch] = issue_summary(km, m, batch)
+        tsummary["batch%d" % batch]["launches_per_pass"] = nl
 if ttraffic:
     json.dump(ttraffic, open(os.path.join(dst, tag + "_train_pmc_traffic.json"), "w"), indent=1)
 if tsummary:

@@ -221,7 +221,8 @@ def _sync_bn_worker(rank, world, port, q, backend):
     # the fit loop: data set on every replica's device, shards of each 12-site batch gathered there, the loss
     # riding in the gradient all-reduce and read once per epoch
     hist = dp.fit(x, y.astype(np.int32), batch_size=12, epochs=2, shuffle=True, seed=5)
-    losses += hist["loss"]
+    losses += hist["loss"] + hist["accuracy"] + hist["auc"]     # the metrics of the epoch's training-mode outputs
+    assert all(0.0 <= v <= 1.0 for v in hist["accuracy"] + hist["auc"])
     assert dp.backend._data is None                 # the device copy does not outlive fit
     torch.cuda.synchronize()
     if rank == 0:
@@ -353,9 +354,12 @@ def test_fit_with_the_data_set_on_the_device_equals_the_host_loop():
         finally:
             if not resident:
                 NativeBackend.set_dataset = orig
-        runs.append((h.history["loss"], m.get_weights()))
+        # `accuracy` and `auc` as Keras logs them (trainer.py:308): over the epoch's training-mode outputs
+        assert list(h.history) == ["loss", "accuracy", "auc", "lr"]
+        runs.append((h.history["loss"] + h.history["accuracy"] + h.history["auc"], m.get_weights()))
         m.close()
     (la, wa), (lb, wb) = runs
     assert np.allclose(la, lb, rtol=2e-4), (la, lb)
+    assert all(0.0 <= v <= 1.0 for v in la[2:])
     for a, c in zip(wa, wb):
         assert np.abs(a - c).max() < 2e-4 * max(1.0, np.abs(c).max())
