@@ -23,8 +23,10 @@ Also reported on the same line (N = 1):
   streamed_from_host  the same model with NumPy arrays in and out (PCIe included).
   proteome     many small proteins per call through dptm_score_proteins_device: window
                assembly + ESM row gather on the device (BASELINE north_star 1 and 4).
-  sweep        BASELINE config 4 on one GPU: 17 weight sets over 262,144 resident sites.
-  train        BASELINE config 5 on one GPU: training step at batch 64, 8,192 and 32,768, and the Model.fit loop around it.
+  sweep        BASELINE config 4 on one GPU: 17 weight sets over 262,144 resident sites (every site of every type
+               checked: finite, rows sum to 1, types pairwise distinct); sweep_1m: the same over 1,000,000 sites.
+  train        BASELINE config 5 on one GPU: training step at batch 64, 8,192 and 32,768, the Model.fit loop around
+               it, and the torch-CPU restatement of the step on the host cores (train.cpu_baseline).
 Other modes (`--types T`, `--train`, `--proteome`) print their own single line and shard over
 ranks the same way.
 """
