@@ -30,6 +30,7 @@ EXPORTS = (
     "dptm_score_device_noalloc", "dptm_noalloc_max_sites",
     "dptm_profile_begin", "dptm_profile_end", "dptm_chunk_sites", "dptm_last_error",
     "dptm_set_precision", "dptm_convert_rows", "dptm_trainer_create", "dptm_trainer_destroy", "dptm_trainer_forward_backward",
+    "dptm_trainer_forward_backward_rows",
     "dptm_trainer_grad_buffer", "dptm_trainer_param_floats", "dptm_trainer_apply",
     "dptm_trainer_get_weights", "dptm_trainer_get_grads", "dptm_trainer_get_proba",
     "dptm_trainer_get_optimizer_state", "dptm_trainer_set_optimizer_state",
@@ -165,6 +166,8 @@ def load_library() -> C.CDLL:
     lib.dptm_trainer_forward_backward.restype = C.c_int
     lib.dptm_trainer_forward_backward.argtypes = [vp, u8p, u8p, u8p, f32p, f32p, i32p, i64,
                                                   C.POINTER(TrainOpts), C.POINTER(C.c_float), vp]
+    lib.dptm_trainer_forward_backward_rows.restype = C.c_int
+    lib.dptm_trainer_forward_backward_rows.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, C.POINTER(TrainOpts), vp, vp, vp]
     lib.dptm_trainer_grad_buffer.restype = C.c_int
     lib.dptm_trainer_grad_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     lib.dptm_trainer_param_floats.restype = C.c_int64
@@ -463,6 +466,19 @@ class Trainer:
             raise err
         _check_t(self._lib, rc, "dptm_trainer_forward_backward")
         return float(loss.value) if want_loss else None
+
+    def forward_backward_rows(self, tok21, tok33, tok51, strct, esm, labels, n_data: int, rows, n: int, opts: TrainOpts,
+                              loss_dev_out=0, proba_dev_out=0, stream=0) -> None:
+        """The step on rows ``rows[0..n)`` (device int64) of a device-resident data set; loss and class probabilities
+        are left at the given device addresses (0: not wanted).  All arguments but ``n_data`` / ``n`` are device addresses."""
+        p = lambda a: C.c_void_p(a or None)
+        rc = self._lib.dptm_trainer_forward_backward_rows(
+            self._h, p(tok21), p(tok33), p(tok51), p(strct), p(esm), p(labels), n_data, p(rows), n, C.byref(opts),
+            p(loss_dev_out), p(proba_dev_out), p(stream))
+        err, self._ar_error = getattr(self, "_ar_error", None), None
+        if err is not None:
+            raise err
+        _check_t(self._lib, rc, "dptm_trainer_forward_backward_rows")
 
     def loss_buffer(self) -> int:
         """Device address of the step's loss (one float32, written by forward_backward in stream order)."""

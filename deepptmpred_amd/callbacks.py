@@ -153,18 +153,10 @@ def roc_auc(labels: np.ndarray, scores: np.ndarray) -> float:
     n_pos, n_neg = int(labels.sum()), int((~labels).sum())
     if n_pos == 0 or n_neg == 0:
         return float("nan")
-    order = np.argsort(scores, kind="mergesort")
-    s = scores[order]
-    ranks = np.empty(len(s), dtype=np.float64)
-    i = 0
-    while i < len(s):
-        j = i
-        while j + 1 < len(s) and s[j + 1] == s[i]:
-            j += 1
-        ranks[i:j + 1] = 0.5 * (i + j) + 1.0
-        i = j + 1
-    r = np.empty(len(s), dtype=np.float64)
-    r[order] = ranks
+    # average ranks (1-based) with ties sharing the mean of their positions
+    _, inverse, counts = np.unique(scores, return_inverse=True, return_counts=True)
+    last = np.cumsum(counts).astype(np.float64)             # rank of the last member of each group of equal scores
+    r = (last - 0.5 * (counts - 1))[inverse]
     return float((r[labels].sum() - n_pos * (n_pos + 1) / 2.0) / (n_pos * n_neg))
 
 

@@ -148,6 +148,9 @@ struct dptm_trainer {
     float *dconcat, *d512a, *d512b, *d256a, *d256b, *d128;
     int64_t step = 0;
     int64_t last_n = 0;
+    // staging of dptm_trainer_forward_backward_rows (one allocation, made by its first call): max_batch rows of
+    // [esm 1280 f | struct 8 f | label i32 | codes 21 + 33 + 51]
+    void* stage = nullptr;
     unsigned* d_step = nullptr;           // per-step scalars (StepParam)
     // captured graph of one forward_backward: replayed while the call's shape, buffers and options repeat
     struct GraphKey {
@@ -618,7 +621,7 @@ void dptm_trainer_destroy(dptm_trainer* t) {
         for (int b = 0; b < 3; ++b)
             if (t->ev_join[ph][b]) (void)hipEventDestroy(t->ev_join[ph][b]);
     }
-    void* bufs[] = {t->W, t->G, t->M, t->V, t->trainable, t->arena.base, t->d_step, t->P, t->pack_jobs};
+    void* bufs[] = {t->W, t->G, t->M, t->V, t->trainable, t->arena.base, t->d_step, t->P, t->pack_jobs, t->stage};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
     if (t->stream) (void)hipStreamDestroy(t->stream);
@@ -1030,14 +1033,9 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
 // DPTM_TRAIN_GRAPH=1 the launch sequence (about 300 small kernels over four streams) is captured into a
 // graph the second time a call repeats the previous call's batch size, buffers, dropout rates, l2 and
 // stream, and replayed from then on.  Off by default: on this stack eager issue is the faster of the two.
-int dptm_trainer_forward_backward(dptm_trainer* t, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
-                                  const float* strct, const float* esm, const int32_t* labels, int64_t n,
-                                  const dptm_train_opts* o, float* loss_out, void* stream) try {
-    if (!t || !o) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward: NULL argument");
-    if (n < 1 || n > t->max_batch) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward: batch size outside 1..max_batch");
-    if (!tok21 || !tok33 || !tok51 || !strct || !esm || !labels) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward: NULL buffer");
-    T_TRY(hipSetDevice(t->device));
-    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : t->stream;
+static int forward_backward_on(dptm_trainer* t, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
+                               const float* strct, const float* esm, const int32_t* labels, int64_t n,
+                               const dptm_train_opts* o, hipStream_t st) {
     const float ng = o->n_global > 0 ? (float)o->n_global : (float)n;
     t->n_local = n;
     t->n_global = o->n_global > 0 ? o->n_global : n;
@@ -1092,6 +1090,19 @@ int dptm_trainer_forward_backward(dptm_trainer* t, const uint8_t* tok21, const u
         }
     }
     t->last_n = n;
+    return DPTM_OK;
+}
+
+int dptm_trainer_forward_backward(dptm_trainer* t, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
+                                  const float* strct, const float* esm, const int32_t* labels, int64_t n,
+                                  const dptm_train_opts* o, float* loss_out, void* stream) try {
+    if (!t || !o) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward: NULL argument");
+    if (n < 1 || n > t->max_batch) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward: batch size outside 1..max_batch");
+    if (!tok21 || !tok33 || !tok51 || !strct || !esm || !labels) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward: NULL buffer");
+    T_TRY(hipSetDevice(t->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : t->stream;
+    const int rc = forward_backward_on(t, tok21, tok33, tok51, strct, esm, labels, n, o, st);
+    if (rc) return rc;
     if (loss_out) {
         T_TRY(hipMemcpyAsync(loss_out, t->d_loss, sizeof(float), hipMemcpyDeviceToHost, st));
         T_TRY(hipStreamSynchronize(st));
@@ -1099,6 +1110,46 @@ int dptm_trainer_forward_backward(dptm_trainer* t, const uint8_t* tok21, const u
     return DPTM_OK;
 } catch (...) {
     return on_texception("dptm_trainer_forward_backward");
+}
+
+// The step on rows[0..n) of a data set that lives on the device: one gather launch into the trainer's staging buffers,
+// the step, one launch that leaves the loss and the class probabilities at the caller's device addresses.  Nothing
+// here waits for the GPU.
+int dptm_trainer_forward_backward_rows(dptm_trainer* t, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
+                                       const float* strct, const float* esm, const int32_t* labels, int64_t n_data,
+                                       const int64_t* rows, int64_t n, const dptm_train_opts* o, float* loss_dev_out,
+                                       float* proba_dev_out, void* stream) try {
+    if (!t || !o || !rows) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward_rows: NULL argument");
+    if (n < 1 || n > t->max_batch) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward_rows: batch size outside 1..max_batch");
+    if (n_data < 1) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward_rows: empty data set");
+    if (!tok21 || !tok33 || !tok51 || !strct || !esm || !labels) return tfail(DPTM_EINVAL, "dptm_trainer_forward_backward_rows: NULL buffer");
+    T_TRY(hipSetDevice(t->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : t->stream;
+    const size_t B = (size_t)t->max_batch;
+    const size_t off_struct = B * 1280 * sizeof(float), off_lab = off_struct + B * 8 * sizeof(float);
+    const size_t off21 = off_lab + B * sizeof(int32_t), off33 = off21 + ((B * 21 + 15) & ~(size_t)15);
+    const size_t off51 = off33 + ((B * 33 + 15) & ~(size_t)15), total = off51 + B * 51;
+    if (!t->stage && hipMalloc(&t->stage, total) != hipSuccess) {
+        t->stage = nullptr;
+        return tfail(DPTM_ENOMEM, "dptm_trainer_forward_backward_rows: staging buffers");
+    }
+    char* base = static_cast<char*>(t->stage);
+    GatherRowsArgs g;
+    g.tok21 = tok21; g.tok33 = tok33; g.tok51 = tok51; g.strct = strct; g.esm = esm; g.labels = labels;
+    g.rows = rows; g.n_data = n_data;
+    g.esm_out = reinterpret_cast<float*>(base);
+    g.strct_out = reinterpret_cast<float*>(base + off_struct);
+    g.labels_out = reinterpret_cast<int32_t*>(base + off_lab);
+    g.tok21_out = reinterpret_cast<uint8_t*>(base + off21);
+    g.tok33_out = reinterpret_cast<uint8_t*>(base + off33);
+    g.tok51_out = reinterpret_cast<uint8_t*>(base + off51);
+    T_TRY(t_gather_rows(g, n, st));
+    const int rc = forward_backward_on(t, g.tok21_out, g.tok33_out, g.tok51_out, g.strct_out, g.esm_out, g.labels_out, n, o, st);
+    if (rc) return rc;
+    T_TRY(t_step_outputs(t->d_loss, loss_dev_out, t->proba, proba_dev_out, n, st));
+    return DPTM_OK;
+} catch (...) {
+    return on_texception("dptm_trainer_forward_backward_rows");
 }
 
 // Arms the per-kernel clocks: until dptm_trainer_profile_end the step's branches run one after another on one

@@ -95,6 +95,18 @@ hipError_t t_pool_fwd(const float* x, const float* w, const float* bias, float* 
                       float* alpha_save, int64_t samples, int wlen, hipStream_t st);
 hipError_t t_pool_bwd(const float* x, const float* w, const float* dout, int64_t ldd, int col_off, const float* a_save,
                       const float* alpha_save, float* dx, float* dw, float* db, int64_t samples, int wlen, hipStream_t st);
+struct GatherRowsArgs {
+    const uint8_t *tok21, *tok33, *tok51;
+    const float *strct, *esm;
+    const int32_t* labels;
+    const int64_t* rows;
+    int64_t n_data;
+    uint8_t *tok21_out, *tok33_out, *tok51_out;
+    float *strct_out, *esm_out;
+    int32_t* labels_out;
+};
+hipError_t t_gather_rows(const GatherRowsArgs& a, int64_t n, hipStream_t st);
+hipError_t t_step_outputs(const float* loss, float* loss_out, const float* proba, float* proba_out, int64_t n, hipStream_t st);
 hipError_t t_head_loss(const float* x, const float* W, const float* bias, const int32_t* labels, int64_t n,
                        const unsigned* step_params, float* proba, float* loss, float* dx, float* dW, float* db, hipStream_t st);
 hipError_t t_adamw(float* w, const float* g, float* m, float* v, const uint8_t* trainable, float stat_scale, int64_t n,

@@ -1314,6 +1314,39 @@ hipError_t t_head_loss(const float* x, const float* W, const float* bias, const 
     }
     return hipGetLastError();
 }
+// Rows rows[0..n) of a device-resident data set -> the trainer's staging buffers (one workgroup per row: the 1280-float
+// ESM row as 16-byte pieces, the 8 structure floats, the 21 + 33 + 51 window codes, the label).  A row index outside
+// the data set is clamped into it (the kernel never reads beyond the arrays whatever the index buffer holds).
+__global__ __launch_bounds__(256) void gather_rows_kernel(GatherRowsArgs a) {
+    const int64_t i = blockIdx.x;
+    int64_t r = a.rows[i];
+    r = r < 0 ? 0 : (r >= a.n_data ? a.n_data - 1 : r);
+    const int tid = threadIdx.x;
+    const f32x4* es = reinterpret_cast<const f32x4*>(a.esm + r * 1280);
+    f32x4* ed = reinterpret_cast<f32x4*>(a.esm_out + i * 1280);
+    for (int k = tid; k < 320; k += 256) ed[k] = es[k];
+    if (tid < 8) a.strct_out[i * 8 + tid] = a.strct[r * 8 + tid];
+    if (tid >= 64 && tid < 64 + 21) a.tok21_out[i * 21 + (tid - 64)] = a.tok21[r * 21 + (tid - 64)];
+    if (tid >= 96 && tid < 96 + 33) a.tok33_out[i * 33 + (tid - 96)] = a.tok33[r * 33 + (tid - 96)];
+    if (tid >= 160 && tid < 160 + 51) a.tok51_out[i * 51 + (tid - 160)] = a.tok51[r * 51 + (tid - 160)];
+    if (tid == 255) a.labels_out[i] = a.labels[r];
+}
+hipError_t t_gather_rows(const GatherRowsArgs& a, int64_t n, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)n), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+// the step's loss and class probabilities to addresses of the caller's, one launch
+__global__ void step_outputs_kernel(const float* loss, float* loss_out, const float* proba, float* proba_out, int64_t n2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (proba_out && i < n2) proba_out[i] = proba[i];
+    if (loss_out && i == 0) loss_out[0] = loss[0];
+}
+hipError_t t_step_outputs(const float* loss, float* loss_out, const float* proba, float* proba_out, int64_t n, hipStream_t st) {
+    if (!loss_out && !proba_out) return hipSuccess;
+    const int64_t n2 = proba_out ? 2 * n : 1;
+    hipLaunchKernelGGL(step_outputs_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, loss, loss_out, proba, proba_out, n2);
+    return hipGetLastError();
+}
 __global__ void set_step_kernel(unsigned* step_params, unsigned seed, float n_global, float n_pos_global) {
     if (threadIdx.x == 0) {
         step_params[kStepSeed] = seed;

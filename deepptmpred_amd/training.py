@@ -151,8 +151,6 @@ class NativeBackend:
             data.append(t.from_numpy(np.ascontiguousarray(labels, dtype=np.int32)).to(self.device))
         self._data = data
         self._data_key = key
-        self._loss_view = self._wrap(self.trainer.loss_buffer(), 1)
-        self._proba_view = self._wrap(self.trainer.proba_buffer(), 2 * self.trainer.max_batch)
         return True
 
     def drop_dataset(self) -> None:
@@ -179,22 +177,21 @@ class NativeBackend:
         its class probabilities -- the training-mode outputs -- to ``proba_out`` (2 floats per row).
         Nothing here waits for the GPU."""
         t = self.torch
-        d = self._staging()
         n = int(idx_dev.numel())
         o = _native.TrainOpts()
         o.seed = seed & 0xFFFFFFFF
         o.rate_embed, o.rate_conv, o.rate_tb, o.rate_dense = rates.embed, rates.conv, rates.tb, rates.dense
         o.n_global, o.n_pos_global = int(n_global), int(n_pos_global)
         o.l2, o.l2_scale = l2, l2_scale
+        a = self._data
+        if not idx_dev.is_contiguous():
+            idx_dev = idx_dev.contiguous()
         with t.cuda.stream(self.stream):
-            for buf, a in zip(d, self._data):
-                t.index_select(a, 0, idx_dev, out=buf[:n])
-            self.trainer.forward_backward(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
-                                          d[4].data_ptr(), d[5].data_ptr(), n, o, False, self.stream.cuda_stream)
-            if loss_out is not None:
-                loss_out.copy_(self._loss_view, non_blocking=True)
-            if proba_out is not None:
-                proba_out.copy_(self._proba_view[:2 * n], non_blocking=True)
+            # one gather launch, the step, one launch for the loss and the probabilities (dptm_trainer_forward_backward_rows)
+            self.trainer.forward_backward_rows(a[0].data_ptr(), a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(),
+                                               a[4].data_ptr(), a[5].data_ptr(), int(a[5].numel()), idx_dev.data_ptr(), n, o,
+                                               loss_out.data_ptr() if loss_out is not None else 0,
+                                               proba_out.data_ptr() if proba_out is not None else 0, self.stream.cuda_stream)
 
     def allreduce_floats(self, dev_tensor, group=None) -> None:
         """Sum of a device tensor over the replicas, in the order of the backend's stream."""

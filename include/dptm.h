@@ -325,6 +325,19 @@ int dptm_trainer_loss_buffer(dptm_trainer* t, float** dev_ptr);
  * copies once per epoch; dptm_trainer_get_proba is the host copy that waits. */
 int dptm_trainer_proba_buffer(dptm_trainer* t, float** dev_ptr);
 
+/* dptm_trainer_forward_backward on rows[0..n) (int64 indices in DEVICE memory) of a data set that lives on the device:
+ * tok21 [n_data][21] ... labels [n_data] as in dptm_trainer_forward_backward, n <= max_batch.  One launch gathers the
+ * rows into staging buffers of the trainer's (allocated by the first call: 5.3 KB per site of max_batch), the step
+ * runs on them, and one more launch leaves the step's loss (1 float) at loss_dev_out and its class probabilities
+ * (n x 2 floats, training-mode outputs) at proba_dev_out -- DEVICE addresses, either may be NULL.  Everything is
+ * ordered on `stream`; nothing waits for the GPU.  An index outside [0, n_data) is clamped into it.  This is the
+ * body of Keras' model.fit loop (pred/train_PTM/trainer.py:332-339: shuffled batches of a resident training set,
+ * per-batch losses and metrics that only surface per epoch) without a host round trip or a per-batch upload. */
+int dptm_trainer_forward_backward_rows(dptm_trainer* t, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
+                                       const float* strct, const float* esm, const int32_t* labels, int64_t n_data,
+                                       const int64_t* rows, int64_t n, const dptm_train_opts* opts, float* loss_dev_out,
+                                       float* proba_dev_out, void* stream);
+
 /* Data-parallel jobs: copies the step's loss (dptm_trainer_loss_buffer) into a float of the gradient buffer that no
  * parameter uses -- the last float of the buffer, padding behind the head bias -- in stream order, and returns that
  * float's index in `slot`.  The ONE all-reduce of the gradient bucket then also sums the replicas' loss shares, and a

@@ -363,3 +363,51 @@ def test_fit_with_the_data_set_on_the_device_equals_the_host_loop():
     assert all(0.0 <= v <= 1.0 for v in la[2:])
     for a, c in zip(wa, wb):
         assert np.abs(a - c).max() < 2e-4 * max(1.0, np.abs(c).max())
+
+
+def test_step_on_rows_of_a_resident_data_set_equals_the_step_on_the_gathered_batch():
+    """dptm_trainer_forward_backward_rows: gather on the device + step + loss / probabilities left at device
+    addresses, against dptm_trainer_forward_backward on the same rows gathered on the host.  Same kernels on the same
+    values: gradients, loss and probabilities must be equal to rounding of the float atomics (1e-5 of the largest
+    gradient).  Second call with fewer rows; an index beyond the data set is clamped to its last row."""
+    import torch
+    n_data = 300
+    w = spec.synthetic_weights(9)
+    x = spec.synthetic_inputs(n_data, 17)
+    y = (np.random.default_rng(4).random(n_data) < 0.3).astype(np.int64)
+    tr = _native.Trainer(spec.pack_blob(w), max_batch=128)
+    d, lab = _device_batch(x, y)
+    rates = (1e-4, 0.3, 0.1, 0.3)
+    rng = np.random.default_rng(6)
+    for n, bad in ((100, False), (37, True)):
+        rows = rng.permutation(n_data)[:n].astype(np.int64)
+        sent = rows.copy()
+        if bad:
+            sent[5] = n_data + 1000          # clamped to the last row
+            rows[5] = n_data - 1
+        o = _opts(31, rates, y[rows])
+        rows_dev = torch.from_numpy(sent).cuda()
+        loss_dev = torch.full((1,), -1.0, device="cuda")
+        proba_dev = torch.full((n, 2), -1.0, device="cuda")
+        torch.cuda.synchronize()
+        tr.forward_backward_rows(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+                                 lab.data_ptr(), n_data, rows_dev.data_ptr(), n, o, loss_dev.data_ptr(), proba_dev.data_ptr())
+        torch.cuda.synchronize()
+        g_rows, p_rows, l_rows = tr.get_grads(), proba_dev.cpu().numpy(), float(loss_dev.cpu()[0])
+        assert np.allclose(tr.get_proba(n), p_rows, atol=0) and abs(p_rows.sum(axis=1) - 1).max() < 1e-5
+        g, lg = _device_batch([a[rows] for a in x], y[rows])
+        loss = tr.forward_backward(g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), g[3].data_ptr(), g[4].data_ptr(),
+                                   lg.data_ptr(), n, o)
+        torch.cuda.synchronize()
+        g_ref = tr.get_grads()
+        assert abs(loss - l_rows) < 1e-6 * max(1.0, abs(loss)), (loss, l_rows)
+        assert np.abs(tr.get_proba(n) - p_rows).max() < 1e-6
+        assert np.abs(g_rows - g_ref).max() < 1e-5 * np.abs(g_ref).max()
+    # the outputs are optional
+    tr.forward_backward_rows(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+                             lab.data_ptr(), n_data, rows_dev.data_ptr(), 37, o)
+    torch.cuda.synchronize()
+    with pytest.raises(Exception):
+        tr.forward_backward_rows(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+                                 lab.data_ptr(), n_data, rows_dev.data_ptr(), 129, o)       # beyond max_batch
+    tr.close()
