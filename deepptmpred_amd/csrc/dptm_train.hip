@@ -82,6 +82,12 @@ struct PMap {
             }
             p.poolk = add(kD); p.poolb = add(1);
         }
+        // column-sum slots by stage, not by branch: the three branches' sums of one stage are then one contiguous range,
+        // which synchronised BatchNorm sums over the replicas with ONE collective
+        for (int b = 0; b < 3; ++b) {
+            br[b].bn1.slot = b;
+            br[b].bn2.slot = 3 + b;
+        }
         strct.k = add(kStruct * kStructUnits); strct.b = add(kStructUnits); strct.bn = add_bn(kStructUnits);
         esm1.k = add((int64_t)kEsm * kEsm1); esm1.b = add(kEsm1); esm1.bn = add_bn(kEsm1);
         esm2.k = add(kEsm1 * kEsm2); esm2.b = add(kEsm2);
@@ -131,11 +137,15 @@ struct dptm_trainer {
     float* d_loss = nullptr;
     // column sums of every BatchNorm, forward [slot] and backward [kBnLayers + slot], 1024 floats each: zeroed once per step
     float* bn_slots = nullptr;
+    // synchronised BatchNorm: the backward sums of the WHOLE batch, [kBnLayers][1024] like the second half of bn_slots
+    // (which keeps this replica's share for the parameter gradients)
+    float* bn_all = nullptr;
+    hipEvent_t ev_sync[4][4] = {};        // stage joins of the branch streams and the per-site lane around a packed collective:
+                                          // [point][W=21 | W=33 | main stream after the sum | per-site lane]
     // Scratch of one concurrent lane of the step: the three sequence branches run on side streams next to
     // the per-site layers, so each owns its gradient scratch ([rows][64] / [rows][256]) and BatchNorm sums.
     struct Scratch {
         f32x4_tr *dx1 = nullptr, *dz1 = nullptr;   // chain-tiled gradients handed from one backward kernel to the next
-        float* bnsums_all = nullptr;
         float* part = nullptr;            // partial parameter gradients of the fused backward kernel, one slab per workgroup
         float* row_part = nullptr;        // the same for the row-wise launches of a large batch: [2 blocks][kRowMaxParts][kRowPartStride]
     };
@@ -215,11 +225,11 @@ int alloc_acts(dptm_trainer* t) {
           need(t->emi, 1024) && need(t->e1, B * 512) && need(t->e2a, B * 256) && need(t->concat, B * 576) &&
           need(t->t1a, B * 512) && need(t->t1y, B * 512) && need(t->t1mi, 1024) && need(t->t1z, B * 512) &&
           need(t->t2a, B * 256) && need(t->t2y, B * 256) && need(t->t2mi, 512) && need(t->t2z, B * 256) &&
-          need(t->proba, B * 2) && need(t->d_loss, 64) && need(t->bn_slots, 2 * kBnLayers * 1024);
+          need(t->proba, B * 2) && need(t->d_loss, 64) && need(t->bn_slots, 2 * kBnLayers * 1024) &&
+          need(t->bn_all, kBnLayers * 1024);
     ok = ok && t->bn_slots == t->d_loss + 64;      // one fill clears both every step
     for (int b = 0; b < 4; ++b) {
         dptm_trainer::Scratch& s = t->sc[b];
-        ok &= need(s.bnsums_all, 1024);
         if (b == 3) break;
         const size_t RP = (size_t)t_tile_rows_max(B, kW[b]);
         float *d1 = nullptr, *d2 = nullptr;
@@ -243,7 +253,7 @@ size_t arena_bytes(int64_t B) {
         f += (size_t)2 * kRowMaxParts * kRowPartStride;             // partial gradients of the row-wise launches
     }
     f += (size_t)B * (128 * 2 + 512 * 3 + 256 + 576 + 512 * 3 + 256 * 3 + 2);
-    f += (4 + 2 * 10) * 1024 + 64 + (size_t)B * (576 + 1024 + 512 + 128);
+    f += (4 + 3 * 10) * 1024 + 64 + (size_t)B * (576 + 1024 + 512 + 128);
     return f * sizeof(float) + (size_t)640 * 256 + (1 << 20);   // + per-allocation rounding slack
 }
 
@@ -267,15 +277,23 @@ int replica_sum(const Ctx& c, float* buf, int64_t count) {
     return DPTM_OK;
 }
 
+// Which half of a BatchNorm call to run.  kBnSums / kBnApply: the column sums only / the layer itself from sums that the
+// caller has summed over the replicas in between (synchronised BatchNorm packs several layers into one collective).
+enum BnPart { kBnWhole, kBnSums, kBnApply };
+
 // BatchNorm in training mode on y [rows][cols] -> z (may live inside a wider buffer)
-int bn_train_fwd(const Ctx& c, const float* y, float* z, int64_t ldz, int zoff, int64_t rows, int cols, const BnP& bn, float* mi) {
+int bn_train_fwd(const Ctx& c, const float* y, float* z, int64_t ldz, int zoff, int64_t rows, int cols, const BnP& bn, float* mi,
+                 BnPart part = kBnWhole) {
     float* stats = c.t->bn_slots + (size_t)bn.slot * 1024;
-    T_TRY(t_colsum2(y, nullptr, rows, cols, stats, c.st));
-    int rc = replica_sum(c, stats, 2 * cols);
-    if (rc) return rc;
+    if (part != kBnApply) T_TRY(t_colsum2(y, nullptr, rows, cols, stats, c.st));
+    if (part == kBnWhole) {
+        int rc = replica_sum(c, stats, 2 * cols);
+        if (rc) return rc;
+    }
     // the batch statistics ride in the (otherwise unused) moving-stat slots of the gradient buffer
-    T_TRY(t_bn_fwd(y, z, rows, cols, stats, global_rows(c.t, rows), mi, c.g(bn.mean), c.g(bn.var), c.w(bn.gamma), c.w(bn.beta), ldz,
-                   zoff, c.st));
+    if (part != kBnSums)
+        T_TRY(t_bn_fwd(y, z, rows, cols, stats, global_rows(c.t, rows), mi, c.g(bn.mean), c.g(bn.var), c.w(bn.gamma), c.w(bn.beta), ldz,
+                       zoff, c.st));
     return DPTM_OK;
 }
 
@@ -283,15 +301,19 @@ int bn_train_fwd(const Ctx& c, const float* y, float* z, int64_t ldz, int zoff, 
 // input gradient needs the sums over the WHOLE batch, the parameter gradients this replica's share only
 // (the gradient all-reduce adds the shares up).
 int bn_train_bwd(const Ctx& c, const float* dz, int64_t lddz, int dzoff, const float* y, float* dy, int64_t rows, int cols,
-                 const float* mi, const BnP& bn) {
+                 const float* mi, const BnP& bn, BnPart part = kBnWhole) {
     float* sums = c.t->bn_slots + (size_t)(kBnLayers + bn.slot) * 1024;
-    T_TRY(t_bn_bwd_reduce(dz, lddz, dzoff, y, rows, cols, mi, sums, c.st));
+    if (part != kBnApply) T_TRY(t_bn_bwd_reduce(dz, lddz, dzoff, y, rows, cols, mi, sums, c.st));
+    if (part == kBnSums) return DPTM_OK;
     const float* all = sums;
     if (c.t->ar_fn) {
-        T_TRY(hipMemcpyAsync(c.s->bnsums_all, sums, 2 * cols * sizeof(float), hipMemcpyDeviceToDevice, c.st));
-        int rc = replica_sum(c, c.s->bnsums_all, 2 * cols);
-        if (rc) return rc;
-        all = c.s->bnsums_all;
+        float* whole = c.t->bn_all + (size_t)bn.slot * 1024;
+        if (part == kBnWhole) {
+            T_TRY(hipMemcpyAsync(whole, sums, 2 * cols * sizeof(float), hipMemcpyDeviceToDevice, c.st));
+            int rc = replica_sum(c, whole, 2 * cols);
+            if (rc) return rc;
+        }
+        all = whole;
     }
     T_TRY(t_bn_bwd_apply(dz, lddz, dzoff, y, dy, rows, cols, mi, c.w(bn.gamma), all, global_rows(c.t, rows), sums,
                          c.g(bn.gamma), c.g(bn.beta), c.st));
@@ -361,8 +383,8 @@ ConvArgs conv_args(const Ctx& c, int b, const uint8_t* tok, int64_t B, const uns
     float* own1 = t->bn_slots + (size_t)(kBnLayers + p.bn1.slot) * 1024;
     float* own2 = t->bn_slots + (size_t)(kBnLayers + p.bn2.slot) * 1024;
     // with synchronised BatchNorm the sums of the whole batch live in a second buffer (filled by the all-reduce)
-    const float* all1 = t->ar_fn ? c.s->bnsums_all : own1;
-    const float* all2 = t->ar_fn ? c.s->bnsums_all + 128 : own2;
+    const float* all1 = t->ar_fn ? t->bn_all + (size_t)p.bn1.slot * 1024 : own1;
+    const float* all2 = t->ar_fn ? t->bn_all + (size_t)p.bn2.slot * 1024 : own2;
     f.bb1 = BnBwd{f.stats1, inv_rows, c.w(p.bn1.gamma), c.w(p.bn1.beta), all1, own1, c.g(p.bn1.gamma), c.g(p.bn1.beta)};
     f.bb2 = BnBwd{f.stats2, inv_rows, c.w(p.bn2.gamma), c.w(p.bn2.beta), all2, own2, c.g(p.bn2.gamma), c.g(p.bn2.beta)};
     f.bn1_sums = own1;
@@ -392,25 +414,24 @@ BnFwd bn2_fwd(const Ctx& c, int b, int64_t B) {
 }
 
 // One sequence branch forward (model.py:157-182) in three launches; the cuts sit where a BatchNorm needs the
-// statistics of the whole batch (and, with synchronised BatchNorm, of all replicas).
-int branch_fwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigned* seed, const Rates& rt) {
+// statistics of the whole batch (and, with synchronised BatchNorm, of all replicas).  Launches first..last of the three
+// (synchronised BatchNorm runs the branches stage by stage and sums the three branches' column sums in between).
+int branch_fwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigned* seed, const Rates& rt, int first = 0,
+               int last = 2) {
     dptm_trainer* t = c.t;
     BranchAct& a = t->ba[b];
     const int wl = a.wlen;
     const TileCfg tc = t_tile_cfg(B, wl);
     const ConvArgs cf = conv_args(c, b, tok, B, seed, rt, tc);
-    int rc;
-    {
+    if (first <= 0 && last >= 0) {
         ProfScope ps(c, b * 6 + 0);
         T_TRY(t_conv_a_fwd(cf, wl, tc.NW, c.st));
     }
-    if ((rc = replica_sum(c, cf.stats1, 128))) return rc;
-    {
+    if (first <= 1 && last >= 1) {
         ProfScope ps(c, b * 6 + 1);
         T_TRY(t_conv_b_fwd(cf, wl, tc.NW, c.st));
     }
-    if ((rc = replica_sum(c, cf.stats2, 128))) return rc;
-    {
+    if (first <= 2 && last >= 2) {
         // BN2 + shortcut add, both TransformerBlocks and the attention pooling (model.py:138-141, 172-182)
         TbFwdArgs f;
         f.P = cf.P;
@@ -435,17 +456,17 @@ int branch_fwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
     return DPTM_OK;
 }
 
-// d(concat)[:, b*64 .. +64]  ->  all parameter gradients of branch b, in three launches (+ the partial-sum kernels)
-int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigned* seed, const Rates& rt) {
+// d(concat)[:, b*64 .. +64]  ->  all parameter gradients of branch b, in three launches (+ the partial-sum kernels):
+// launches first..last of them, `plan` carrying what the launches leave to be summed from one call to the next.
+int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigned* seed, const Rates& rt, PartPlan* plan,
+               int first = 0, int last = 2) {
     dptm_trainer* t = c.t;
     BranchAct& a = t->ba[b];
     const BranchP& p = t->pm.br[b];
     const int wl = a.wlen;
     const TileCfg tc = t_tile_cfg(B, wl);
     const ConvArgs cf = conv_args(c, b, tok, B, seed, rt, tc);
-    PartPlan plan;       // the three launches' partial sums are added to the gradients by one launch after the last
-    int rc;
-    {
+    if (first <= 0 && last >= 0) {
         // pooling and both TransformerBlocks backward: d(concat columns of this branch) -> d(x1), BN2 column sums
         TbBwdArgs f;
         f.P = cf.P;
@@ -488,25 +509,16 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
         g.poolw = c.g(p.poolk);
         g.poolb = c.g(p.poolb);
         ProfScope ps(c, b * 6 + 3);
-        T_TRY(t_tb_bwd(f, g, wl, tc.NW, &plan, c.st));
+        T_TRY(t_tb_bwd(f, g, wl, tc.NW, plan, c.st));
     }
     const ConvGrads cg{c.g(p.emb), c.g(p.pos), c.g(p.sck), c.g(p.scb), c.g(p.c3ak), c.g(p.c3ab), c.g(p.c3bk), c.g(p.c3bb)};
-    // the input gradient of a BatchNorm needs the sums over the WHOLE batch, its parameter gradients this replica's share
-    if (t->ar_fn) {
-        T_TRY(hipMemcpyAsync(c.s->bnsums_all + 128, cf.bb2.own, 128 * sizeof(float), hipMemcpyDeviceToDevice, c.st));
-        if ((rc = replica_sum(c, c.s->bnsums_all + 128, 128))) return rc;
-    }
-    {
+    if (first <= 1 && last >= 1) {
         ProfScope ps(c, b * 6 + 4);
-        T_TRY(t_conv_b_bwd(cf, cg, wl, tc.NW, &plan, c.st));
+        T_TRY(t_conv_b_bwd(cf, cg, wl, tc.NW, plan, c.st));
     }
-    if (t->ar_fn) {
-        T_TRY(hipMemcpyAsync(c.s->bnsums_all, cf.bb1.own, 128 * sizeof(float), hipMemcpyDeviceToDevice, c.st));
-        if ((rc = replica_sum(c, c.s->bnsums_all, 128))) return rc;
-    }
-    {
+    if (first <= 2 && last >= 2) {
         ProfScope ps(c, b * 6 + 5);
-        T_TRY(t_conv_a_bwd(cf, cg, wl, tc.NW, &plan, c.st));
+        T_TRY(t_conv_a_bwd(cf, cg, wl, tc.NW, plan, c.st));
     }
     return DPTM_OK;
 }
@@ -621,6 +633,9 @@ void dptm_trainer_destroy(dptm_trainer* t) {
         for (int b = 0; b < 3; ++b)
             if (t->ev_join[ph][b]) (void)hipEventDestroy(t->ev_join[ph][b]);
     }
+    for (auto& stage : t->ev_sync)
+        for (hipEvent_t e : stage)
+            if (e) (void)hipEventDestroy(e);
     void* bufs[] = {t->W, t->G, t->M, t->V, t->trainable, t->arena.base, t->d_step, t->P, t->pack_jobs, t->stage};
     for (void* p : bufs)
         if (p) (void)hipFree(p);
@@ -659,6 +674,9 @@ int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spe
         for (int b = 0; b < 3; ++b)
             if (hipEventCreateWithFlags(&t->ev_join[ph][b], hipEventDisableTiming) != hipSuccess) return bail(DPTM_EHIP, "hipEventCreate failed");
     }
+    for (auto& stage : t->ev_sync)
+        for (hipEvent_t& e : stage)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(DPTM_EHIP, "hipEventCreate failed");
     const size_t pb = (size_t)t->pm.total * sizeof(float);
     if (hipMalloc((void**)&t->W, pb) != hipSuccess || hipMalloc((void**)&t->G, pb) != hipSuccess ||
         hipMalloc((void**)&t->M, pb) != hipSuccess || hipMalloc((void**)&t->V, pb) != hipSuccess ||
@@ -866,11 +884,54 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
     hipStream_t ss = !t->serial ? t->aux[2] : st;      // per-site layers that run next to the branches
     hipStream_t side[3] = {bstream[0], bstream[1], ss};
     // the longest branch first: its launches are then the first the host hands to the device
+    // Synchronised BatchNorm: the three branches advance stage by stage, and between two stages the main stream sums
+    // the column sums all three just produced over the replicas in ONE collective (their slots are contiguous):
+    // 2 collectives per direction for the branches instead of 6.  The input gradient of a BatchNorm needs the sums
+    // over the WHOLE batch (bn_all), its parameter gradients this replica's share (bn_slots).
+    auto stage_sum = [&](int point, int slot0, int nslots, bool backward, bool with_site_lane) -> int {
+        for (int b = 0; b < 2; ++b)
+            if (bstream[b] != st) {
+                T_TRY(hipEventRecord(t->ev_sync[point][b], bstream[b]));
+                T_TRY(hipStreamWaitEvent(st, t->ev_sync[point][b], 0));
+            }
+        if (with_site_lane && ss != st) {
+            T_TRY(hipEventRecord(t->ev_sync[point][3], ss));
+            T_TRY(hipStreamWaitEvent(st, t->ev_sync[point][3], 0));
+        }
+        float* buf = t->bn_slots + (size_t)slot0 * 1024;
+        if (backward) {
+            buf = t->bn_all + (size_t)slot0 * 1024;
+            T_TRY(hipMemcpyAsync(buf, t->bn_slots + (size_t)(kBnLayers + slot0) * 1024, (size_t)nslots * 1024 * sizeof(float),
+                                 hipMemcpyDeviceToDevice, st));
+        }
+        const int r = replica_sum(c, buf, (int64_t)nslots * 1024);
+        if (r) return r;
+        T_TRY(hipEventRecord(t->ev_sync[point][2], st));
+        for (int b = 0; b < 2; ++b)
+            if (bstream[b] != st) T_TRY(hipStreamWaitEvent(bstream[b], t->ev_sync[point][2], 0));
+        if (with_site_lane && ss != st) T_TRY(hipStreamWaitEvent(ss, t->ev_sync[point][2], 0));
+        return DPTM_OK;
+    };
     auto branches = [&](bool forward, int first, int last) -> int {
-        for (int b = last; b >= first; --b) {
-            Ctx cb{t, bstream[b], t->W, t->G, &t->sc[b]};
-            const int r = forward ? branch_fwd(cb, b, tok[b], B, seed, rt) : branch_bwd(cb, b, tok[b], B, seed, rt);
-            if (r) return r;
+        PartPlan plans[3];
+        const bool staged = t->ar_fn != nullptr && first == 0 && last == 2;
+        for (int stage = 0; stage < (staged ? 3 : 1); ++stage) {
+            for (int b = last; b >= first; --b) {
+                Ctx cb{t, bstream[b], t->W, t->G, &t->sc[b]};
+                const int s0 = staged ? stage : 0, s1 = staged ? stage : 2;
+                const int r = forward ? branch_fwd(cb, b, tok[b], B, seed, rt, s0, s1) : branch_bwd(cb, b, tok[b], B, seed, rt, &plans[b], s0, s1);
+                if (r) return r;
+            }
+            if (staged && stage < 2) {
+                // forward: BatchNorm 1 after the first launch, BatchNorm 2 after the second; backward: 2, then 1.  The
+                // structure and ESM layers' BatchNorms (slots 6, 7; their sums are on the per-site lane by then) join the
+                // first collective of either direction: forward slots 0..7 (3..5 are still zero), backward 3..7.
+                const bool first_sum = stage == 0;
+                const int slot0 = forward ? 3 * stage : 3 * (1 - stage);
+                const int nslots = first_sum ? (forward ? 8 : 5) : 3;
+                const int r = stage_sum((forward ? 0 : 2) + stage, slot0, nslots, !forward, first_sum);
+                if (r) return r;
+            }
         }
         return DPTM_OK;
     };
@@ -957,23 +1018,34 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
                   kEsm, none, 512));
         if ((rc = branches(false, 0, 1))) return rc;
     } else {
-        if ((rc = branches(true, 0, 2))) return rc;
-        // structure and ESM layers on the fourth stream, next to the three branches
+        // structure and ESM layers on the fourth stream, next to the three branches.  With synchronised BatchNorm their
+        // column sums are taken BEFORE the branches are enqueued, so that they join the collective behind the branches'
+        // first stage, and the layers themselves follow behind it.
+        const bool packed = t->ar_fn != nullptr;
         Ctx cf{t, ss, t->W, t->G, &t->sc[3]};
-        // struct branch (model.py:187-189)
         auto dense_swish = [&](GemmArgs g, float* act, int64_t lda, hipStream_t s) {     // pre-activation to g.out, swish of it to act
             g.act_out = act; g.lda = lda;
             return t_gemm(g, false, s);
         };
-        T_TRY(dense_swish(ga(strct, 8, c.w(pm.strct.k), 128, c.w(pm.strct.b), t->sa, 128, 0, B, 8, 128), t->sy, 128, ss));
-        if ((rc = bn_train_fwd(cf, t->sy, t->concat, kConcat, 192, B, 128, pm.strct.bn, t->smi))) return rc;
-        T_TRY(t_dropout(t->concat + 192, B, 128, kConcat, 0, seed, 24 + 0, rt.dense, ss));
-        // ESM branch (model.py:191-194)
-        T_TRY(dense_swish(ga(esm, kEsm, c.w(pm.esm1.k), 512, c.w(pm.esm1.b), t->ea, 512, 0, B, kEsm, 512), t->ey, 512, ss));
-        if ((rc = bn_train_fwd(cf, t->ey, t->e1, 512, 0, B, 512, pm.esm1.bn, t->emi))) return rc;
-        T_TRY(t_dropout(t->e1, B, 512, 512, 0, seed, 24 + 1, rt.dense, ss));
-        // swish straight into the concat columns 320..575
-        T_TRY(dense_swish(ga(t->e1, 512, c.w(pm.esm2.k), 256, c.w(pm.esm2.b), t->e2a, 256, 0, B, 512, 256), t->concat + 320, kConcat, ss));
+        // struct branch (model.py:187-189), ESM branch (model.py:191-194); part 0: up to the column sums, 1: from them on
+        auto site_layers_fwd = [&](int part0, int part1) -> int {
+            const BnPart bp = part0 == 0 && part1 == 1 ? kBnWhole : part0 == 0 ? kBnSums : kBnApply;
+            int r;
+            if (part0 == 0) T_TRY(dense_swish(ga(strct, 8, c.w(pm.strct.k), 128, c.w(pm.strct.b), t->sa, 128, 0, B, 8, 128), t->sy, 128, ss));
+            if ((r = bn_train_fwd(cf, t->sy, t->concat, kConcat, 192, B, 128, pm.strct.bn, t->smi, bp))) return r;
+            if (part1 == 1) T_TRY(t_dropout(t->concat + 192, B, 128, kConcat, 0, seed, 24 + 0, rt.dense, ss));
+            if (part0 == 0) T_TRY(dense_swish(ga(esm, kEsm, c.w(pm.esm1.k), 512, c.w(pm.esm1.b), t->ea, 512, 0, B, kEsm, 512), t->ey, 512, ss));
+            if ((r = bn_train_fwd(cf, t->ey, t->e1, 512, 0, B, 512, pm.esm1.bn, t->emi, bp))) return r;
+            if (part1 == 1) {
+                T_TRY(t_dropout(t->e1, B, 512, 512, 0, seed, 24 + 1, rt.dense, ss));
+                // swish straight into the concat columns 320..575
+                T_TRY(dense_swish(ga(t->e1, 512, c.w(pm.esm2.k), 256, c.w(pm.esm2.b), t->e2a, 256, 0, B, 512, 256), t->concat + 320, kConcat, ss));
+            }
+            return DPTM_OK;
+        };
+        if (packed && (rc = site_layers_fwd(0, 0))) return rc;
+        if ((rc = branches(true, 0, 2))) return rc;
+        if ((rc = packed ? site_layers_fwd(1, 1) : site_layers_fwd(0, 1))) return rc;
         if ((rc = join(0))) return rc;              // pooled branch outputs are in concat
         T_TRY(t_dropout(t->concat, B, kConcat, kConcat, 0, seed, 24 + 2, rt.dense, st));
         // trunk (model.py:200-205)
@@ -995,31 +1067,59 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
         T_TRY(t_swish_bwd(t->t1a, t->d512b, t->d512b, B * 512, st));
         T_TRY(t_gemm(ga(t->d512b, 512, c.w(pm.t1.k), 512, nullptr, t->dconcat, kConcat, 0, B, 512, kConcat), true, st));
         T_TRY(t_dropout(t->dconcat, B, kConcat, kConcat, 0, seed, 24 + 2, rt.dense, st));
-        // d(concat) is complete: the sequence branches go backward side by side with the ESM and structure layers below
-        // (each owns its parameters' gradients)
         if ((rc = fork(1))) return rc;
-        if ((rc = branches(false, 0, 2))) return rc;
         // The trunk's two weight gradients wait until here -- nothing on the way to d(concat) needs them -- and run with
         // the ESM / structure layers on the fourth stream, next to the branches instead of holding the whole chip up.
-        // (One stream for all of them: the layers below reuse d512b.)
+        // (One stream for all of them: the layers below reuse d512b.)  With synchronised BatchNorm the lane goes as far as
+        // its two BatchNorms' column sums before the branches are enqueued (they join the collective behind the
+        // branches' first backward stage) and finishes behind it.
         Ctx cs{t, ss, t->W, t->G, &t->sc[3]};
-        T_TRY(t_gemm_tn(gt(t->t1z, 512, 0, t->d256b, 256, 0, c.g(pm.t2.k), 256, c.g(pm.t2.b), B, 512, 256), ss));
-        T_TRY(t_gemm_tn(gt(t->concat, kConcat, 0, t->d512b, 512, 0, c.g(pm.t1.k), 512, c.g(pm.t1.b), B, kConcat, 512), ss));
-        // ESM branch: d(concat[:,320:]) -> swish -> dense2 -> dropout -> BN -> swish -> dense1
-        T_TRY(t_copy_cols(t->d256a, 256, 0, t->dconcat, kConcat, 320, B, 256, false, ss));
-        T_TRY(t_swish_bwd(t->e2a, t->d256a, t->d256a, B * 256, ss));
-        T_TRY(t_gemm_tn(gt(t->e1, 512, 0, t->d256a, 256, 0, c.g(pm.esm2.k), 256, c.g(pm.esm2.b), B, 512, 256), ss));
-        T_TRY(t_gemm(ga(t->d256a, 256, c.w(pm.esm2.k), 256, nullptr, t->d512a, 512, 0, B, 256, 512), true, ss));
-        T_TRY(t_dropout(t->d512a, B, 512, 512, 0, seed, 24 + 1, rt.dense, ss));
-        if ((rc = bn_train_bwd(cs, t->d512a, 512, 0, t->ey, t->d512b, B, 512, t->emi, pm.esm1.bn))) return rc;
-        T_TRY(t_swish_bwd(t->ea, t->d512b, t->d512b, B * 512, ss));
-        T_TRY(t_gemm_tn(gt(esm, kEsm, 0, t->d512b, 512, 0, c.g(pm.esm1.k), 512, c.g(pm.esm1.b), B, kEsm, 512), ss));
-        // struct branch: d(concat[:,192:320]) -> dropout -> BN -> swish -> dense
-        T_TRY(t_copy_cols(t->d128, 128, 0, t->dconcat, kConcat, 192, B, 128, false, ss));
-        T_TRY(t_dropout(t->d128, B, 128, 128, 0, seed, 24 + 0, rt.dense, ss));
-        if ((rc = bn_train_bwd(cs, t->d128, 128, 0, t->sy, t->d512a, B, 128, t->smi, pm.strct.bn))) return rc;
-        T_TRY(t_swish_bwd(t->sa, t->d512a, t->d512a, B * 128, ss));
-        T_TRY(t_gemm_tn(gt(strct, 8, 0, t->d512a, 128, 0, c.g(pm.strct.k), 128, c.g(pm.strct.b), B, 8, 128), ss));
+        auto site_layers_bwd = [&](int part0, int part1) -> int {
+            const BnPart bp = part0 == 0 && part1 == 1 ? kBnWhole : part0 == 0 ? kBnSums : kBnApply;
+            int r;
+            if (part0 == 0) {
+                T_TRY(t_gemm_tn(gt(t->t1z, 512, 0, t->d256b, 256, 0, c.g(pm.t2.k), 256, c.g(pm.t2.b), B, 512, 256), ss));
+                T_TRY(t_gemm_tn(gt(t->concat, kConcat, 0, t->d512b, 512, 0, c.g(pm.t1.k), 512, c.g(pm.t1.b), B, kConcat, 512), ss));
+                // ESM branch: d(concat[:,320:]) -> swish -> dense2 -> dropout -> BN -> swish -> dense1
+                T_TRY(t_copy_cols(t->d256a, 256, 0, t->dconcat, kConcat, 320, B, 256, false, ss));
+                T_TRY(t_swish_bwd(t->e2a, t->d256a, t->d256a, B * 256, ss));
+                T_TRY(t_gemm_tn(gt(t->e1, 512, 0, t->d256a, 256, 0, c.g(pm.esm2.k), 256, c.g(pm.esm2.b), B, 512, 256), ss));
+                T_TRY(t_gemm(ga(t->d256a, 256, c.w(pm.esm2.k), 256, nullptr, t->d512a, 512, 0, B, 256, 512), true, ss));
+                T_TRY(t_dropout(t->d512a, B, 512, 512, 0, seed, 24 + 1, rt.dense, ss));
+            }
+            if (bp != kBnWhole) {
+                // struct branch: d(concat[:,192:320]) -> dropout -> BN -> swish -> dense.  (Its gradient lands in d512a, which
+                // the ESM BatchNorm still reads: in two parts the sums of both come first.)
+                if (part0 == 0) {
+                    T_TRY(t_copy_cols(t->d128, 128, 0, t->dconcat, kConcat, 192, B, 128, false, ss));
+                    T_TRY(t_dropout(t->d128, B, 128, 128, 0, seed, 24 + 0, rt.dense, ss));
+                    if ((r = bn_train_bwd(cs, t->d512a, 512, 0, t->ey, t->d512b, B, 512, t->emi, pm.esm1.bn, kBnSums))) return r;
+                    if ((r = bn_train_bwd(cs, t->d128, 128, 0, t->sy, t->d512a, B, 128, t->smi, pm.strct.bn, kBnSums))) return r;
+                    return DPTM_OK;
+                }
+                if ((r = bn_train_bwd(cs, t->d512a, 512, 0, t->ey, t->d512b, B, 512, t->emi, pm.esm1.bn, kBnApply))) return r;
+                T_TRY(t_swish_bwd(t->ea, t->d512b, t->d512b, B * 512, ss));
+                T_TRY(t_gemm_tn(gt(esm, kEsm, 0, t->d512b, 512, 0, c.g(pm.esm1.k), 512, c.g(pm.esm1.b), B, kEsm, 512), ss));
+                if ((r = bn_train_bwd(cs, t->d128, 128, 0, t->sy, t->d512a, B, 128, t->smi, pm.strct.bn, kBnApply))) return r;
+                T_TRY(t_swish_bwd(t->sa, t->d512a, t->d512a, B * 128, ss));
+                T_TRY(t_gemm_tn(gt(strct, 8, 0, t->d512a, 128, 0, c.g(pm.strct.k), 128, c.g(pm.strct.b), B, 8, 128), ss));
+                return DPTM_OK;
+            }
+            if ((r = bn_train_bwd(cs, t->d512a, 512, 0, t->ey, t->d512b, B, 512, t->emi, pm.esm1.bn))) return r;
+            T_TRY(t_swish_bwd(t->ea, t->d512b, t->d512b, B * 512, ss));
+            T_TRY(t_gemm_tn(gt(esm, kEsm, 0, t->d512b, 512, 0, c.g(pm.esm1.k), 512, c.g(pm.esm1.b), B, kEsm, 512), ss));
+            T_TRY(t_copy_cols(t->d128, 128, 0, t->dconcat, kConcat, 192, B, 128, false, ss));
+            T_TRY(t_dropout(t->d128, B, 128, 128, 0, seed, 24 + 0, rt.dense, ss));
+            if ((r = bn_train_bwd(cs, t->d128, 128, 0, t->sy, t->d512a, B, 128, t->smi, pm.strct.bn))) return r;
+            T_TRY(t_swish_bwd(t->sa, t->d512a, t->d512a, B * 128, ss));
+            T_TRY(t_gemm_tn(gt(strct, 8, 0, t->d512a, 128, 0, c.g(pm.strct.k), 128, c.g(pm.strct.b), B, 8, 128), ss));
+            return DPTM_OK;
+        };
+        // d(concat) is complete: the sequence branches go backward side by side with the ESM and structure layers
+        // (each owns its parameters' gradients)
+        if (packed && (rc = site_layers_bwd(0, 0))) return rc;
+        if ((rc = branches(false, 0, 2))) return rc;
+        if ((rc = packed ? site_layers_bwd(1, 1) : site_layers_bwd(0, 1))) return rc;
     }
     if ((rc = join(1))) return rc;
     if (st != caller) {

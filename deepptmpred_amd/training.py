@@ -12,7 +12,7 @@ data-parallel exchange (one process per GPU):
      (trainer.py:39-44) are computed locally: no collective, no host round trip;
   2. local forward/backward on the replica's contiguous shard (BatchNorm normalises with the
      replica's own batch statistics, or -- ``sync_batchnorm=True`` -- with the global batch's:
-     20 more small all-reduces per step);
+     8 more small all-reduces per step, one per level of dependent BatchNorms and direction);
   3. ONE all-reduce (sum) over the flat fp32 gradient buffer: every tensor's gradient in
      one bucket, with the batch mean/variance of every BatchNorm riding in the slots of
      its (untrained) moving statistics and the replica's loss share in the bucket's spare
@@ -207,14 +207,17 @@ class NativeBackend:
     def enable_sync_batchnorm(self, group=None) -> None:
         """Every BatchNorm then normalises with the statistics of the GLOBAL batch: its column sums are
         all-reduced over ``group`` (RCCL on GPUs) inside the step, on the stream the layer runs on, so
-        N replicas reproduce a one-device run on the whole batch.  20 small collectives per step."""
+        N replicas reproduce a one-device run on the whole batch.  8 small collectives per step (``sync_bn_calls`` counts them)."""
         import torch.distributed as dist
         t = self.torch
         views = {}
 
         on_device = dist.get_backend(group) == "nccl"     # RCCL reduces device memory in stream order
 
+        self.sync_bn_calls = 0
+
         def allreduce(ptr: int, count: int, stream: int) -> None:
+            self.sync_bn_calls += 1
             v = views.get((ptr, count))
             if v is None:
                 v = views[(ptr, count)] = self._wrap(ptr, count)

@@ -293,11 +293,14 @@ int dptm_trainer_apply(dptm_trainer* t, float lr, float weight_decay, float grad
 
 /* Synchronised BatchNorm for data-parallel jobs (no counterpart in the reference, which trains on
  * one device: trainer.py:332).  By default every replica normalises with the statistics of its own
- * shard.  With a callback set, forward_backward hands it every BatchNorm's column sums -- forward:
+ * shard.  With a callback set, forward_backward hands it the BatchNorms' column sums -- forward:
  * [sum x | sum x^2], backward: [sum dz | sum dz*xhat], `count` floats at DEVICE address `buf` --
- * right after the kernel that produced them was enqueued on `stream` (a hipStream_t).  The callback
+ * right after the kernels that produced them were enqueued, on `stream` (a hipStream_t).  The callback
  * must sum the buffer in place over all replicas, ordered on that stream (e.g. an RCCL all-reduce),
- * and return 0; every replica makes the same sequence of calls (20 per step).  The layer then uses
+ * and return 0; every replica makes the same sequence of calls: 8 per step -- the ten BatchNorms sit on
+ * four dependent levels per direction (first / second convolution of the three branches, with the structure
+ * and first ESM layer riding in the first collective of either direction; the two trunk layers), and the
+ * sums of a level are one contiguous buffer of 1,024-float slots (3 to 8 K floats).  The layer then uses
  * the GLOBAL batch (opts->n_global sites) for mean, variance and the backward terms, so N replicas
  * reproduce one device run on the whole batch.  fn = NULL restores per-replica statistics. */
 typedef int (*dptm_allreduce_fn)(void* user, float* buf, int64_t count, void* stream);

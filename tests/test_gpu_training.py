@@ -218,6 +218,8 @@ def _sync_bn_worker(rank, world, port, q, backend):
     dp = DataParallelTrainer(NativeBackend(w, max_batch=24), AdamW(5e-4, 1e-4), DropoutRates.off(),
                              sync_batchnorm=bool(backend))
     losses = [dp.train_on_batch(x, np.eye(2)[y], seed=3 + i) for i in range(2)]
+    if backend:     # synchronised BatchNorm: one collective per level of dependent BatchNorms and direction
+        assert dp.backend.sync_bn_calls == 2 * 8, dp.backend.sync_bn_calls
     # the fit loop: data set on every replica's device, shards of each 12-site batch gathered there, the loss
     # riding in the gradient all-reduce and read once per epoch
     hist = dp.fit(x, y.astype(np.int32), batch_size=12, epochs=2, shuffle=True, seed=5)
