@@ -29,7 +29,7 @@ EXPORTS = (
     "dptm_score_proteins", "dptm_score_proteins_device", "dptm_assemble_proteins_device",
     "dptm_score_device_noalloc", "dptm_noalloc_max_sites",
     "dptm_profile_begin", "dptm_profile_end", "dptm_chunk_sites", "dptm_last_error",
-    "dptm_set_precision", "dptm_convert_rows", "dptm_trainer_create", "dptm_trainer_destroy", "dptm_trainer_forward_backward",
+    "dptm_set_precision", "dptm_convert_rows", "dptm_score_rows16", "dptm_trainer_create", "dptm_trainer_destroy", "dptm_trainer_forward_backward",
     "dptm_trainer_forward_backward_rows",
     "dptm_trainer_grad_buffer", "dptm_trainer_param_floats", "dptm_trainer_apply",
     "dptm_trainer_get_weights", "dptm_trainer_get_grads", "dptm_trainer_get_proba",
@@ -127,6 +127,8 @@ def load_library() -> C.CDLL:
     lib.dptm_destroy.argtypes = [vp]
     lib.dptm_score.restype = C.c_int
     lib.dptm_score.argtypes = [vp, u8p, u8p, u8p, f32p, f32p, i64, f32p]
+    lib.dptm_score_rows16.restype = C.c_int
+    lib.dptm_score_rows16.argtypes = [vp, u8p, u8p, u8p, f32p, vp, i64, f32p]
     lib.dptm_score_protein.restype = C.c_int
     lib.dptm_score_protein.argtypes = [vp, u8p, i64, f32p, i64, i32p, f32p, i64, f32p]
     lib.dptm_score_device.restype = C.c_int
@@ -300,6 +302,21 @@ class Scorer:
         rc = self._lib.dptm_score(self._h, _ptr(tok21), _ptr(tok33), _ptr(tok51), _ptr(strct),
                                   _ptr(esm), n, _ptr(out))
         _check(self._lib, rc, "dptm_score")
+        return out
+
+    def score_rows16(self, tok21, tok33, tok51, strct, esm16) -> np.ndarray:
+        """``score`` with the ESM rows kept as the 16-bit operand values of the scorer's bf16 / f16 mode
+        (``convert_rows``): uint16 ``[n][1280]``."""
+        n = len(tok21)
+        ws = self.spec.window_sizes
+        for a, w, name in ((tok21, ws[0], "tok21"), (tok33, ws[1], "tok33"), (tok51, ws[2], "tok51")):
+            _buffer(a, np.uint8, (n, w), f"dptm_score_rows16: {name}")
+        _buffer(strct, np.float32, (n, self.spec.struct_feature_dim), "dptm_score_rows16: struct")
+        _buffer(esm16, np.uint16, (n, self.spec.esm_dim), "dptm_score_rows16: esm")
+        out = np.empty((n, 2), dtype=np.float32)
+        rc = self._lib.dptm_score_rows16(self._h, _ptr(tok21), _ptr(tok33), _ptr(tok51), _ptr(strct),
+                                         C.c_void_p(esm16.ctypes.data), n, _ptr(out))
+        _check(self._lib, rc, "dptm_score_rows16")
         return out
 
     def score_protein(self, codes, esm_table, positions, strct) -> np.ndarray:

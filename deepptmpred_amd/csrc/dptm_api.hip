@@ -1074,12 +1074,18 @@ int dptm_score_protein_device(dptm_handle* h, const uint8_t* codes, int64_t L, c
     return on_exception("dptm_score_protein_device");
 }
 
-int dptm_score(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
-               const float* strct, const float* esm, int64_t n, float* out) try {
+// dptm_score and dptm_score_rows16: `esm` holds fp32 rows, or (rows16) the 16-bit operand values of the handle's
+// one-operand half-precision mode
+static int score_host_rows(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
+                           const float* strct, const void* esm_rows, bool rows16, int64_t n, float* out) {
     if (!h) return fail(DPTM_EINVAL, "dptm_score: NULL handle");
     if (n < 0) return fail(DPTM_EINVAL, "dptm_score: n < 0");
     if (n == 0) return DPTM_OK;
-    if (!tok21 || !tok33 || !tok51 || !strct || !esm || !out) return fail(DPTM_EINVAL, "dptm_score: NULL buffer");
+    if (!tok21 || !tok33 || !tok51 || !strct || !esm_rows || !out) return fail(DPTM_EINVAL, "dptm_score: NULL buffer");
+    if (rows16 && h->precision != kModeBF16 && h->precision != kModeF16)
+        return fail(DPTM_EINVAL, "dptm_score_rows16: 16-bit input rows need the bf16 or f16 mode (dptm_set_precision)");
+    const float* esm = static_cast<const float*>(esm_rows);            // when !rows16
+    const uint16_t* esm16 = static_cast<const uint16_t*>(esm_rows);    // when rows16
     HIP_TRY(hipSetDevice(h->device));
     int rc = ensure_host_staging(h);
     if (rc) return rc;
@@ -1090,9 +1096,10 @@ int dptm_score(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const
         for (int b = 0; b < 3; ++b)
             HIP_TRY(hipMemcpyAsync(h->s_tok[b], (b == 0 ? tok21 : b == 1 ? tok33 : tok51), n * kWin[b], hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipMemcpyAsync(h->s_strct, strct, n * kStruct * sizeof(float), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(h->s_esm, esm, n * (size_t)kEsm * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->s_esm, esm_rows, n * (size_t)kEsm * (rows16 ? sizeof(uint16_t) : sizeof(float)), hipMemcpyHostToDevice,
+                               h->stream));
         const uint8_t* tok[3] = {h->s_tok[0], h->s_tok[1], h->s_tok[2]};
-        if ((rc = score_chunk(h, h->ws, tok, h->s_strct, h->s_esm, kEsm, nullptr, n, h->s_out, h->stream))) return rc;
+        if ((rc = score_chunk(h, h->ws, tok, h->s_strct, h->s_esm, kEsm, nullptr, n, h->s_out, h->stream, rows16))) return rc;
         HIP_TRY(hipMemcpyAsync(out, h->s_out, n * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         drain.armed = false;
@@ -1124,7 +1131,9 @@ int dptm_score(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const
         const int slot = (int)(i & 1);
         uint8_t* pin = h->pin_in[slot];
         if (i >= 2) HIP_TRY(hipEventSynchronize(h->ev_copied[slot]));   // the pinned block has crossed PCIe
-        if (esm_half)
+        if (rows16)
+            parallel_copy(pin + kPinEsm, esm16 + c0 * (int64_t)kEsm, (size_t)m * kEsm * sizeof(uint16_t));
+        else if (esm_half)
             parallel_convert(reinterpret_cast<uint16_t*>(pin + kPinEsm), esm + c0 * (int64_t)kEsm, m, h->precision);
         else
             parallel_copy(pin + kPinEsm, esm + c0 * (int64_t)kEsm, (size_t)m * kEsm * sizeof(float));
@@ -1149,8 +1158,20 @@ int dptm_score(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const
     if ((rc = retire((int)((i - 1) & 1), prev_c0, prev_m))) return rc;
     drain.armed = false;
     return DPTM_OK;
+}
+
+int dptm_score(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
+               const float* strct, const float* esm, int64_t n, float* out) try {
+    return score_host_rows(h, tok21, tok33, tok51, strct, esm, false, n, out);
 } catch (...) {
     return on_exception("dptm_score");
+}
+
+int dptm_score_rows16(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
+                      const float* strct, const uint16_t* esm16, int64_t n, float* out) try {
+    return score_host_rows(h, tok21, tok33, tok51, strct, esm16, true, n, out);
+} catch (...) {
+    return on_exception("dptm_score_rows16");
 }
 
 int dptm_score_protein(dptm_handle* h, const uint8_t* codes, int64_t L, const float* esm_table,

@@ -181,6 +181,14 @@ int dptm_assemble_proteins_device(dptm_handle* h, const uint8_t* codes, const in
  * bit-identical to converting on the device.  No counterpart in the reference (Keras feeds fp32, predict.py:598-599). */
 int dptm_convert_rows(const float* src, int64_t n, int mode, uint16_t* dst);
 
+/* dptm_score for a caller that KEEPS its ESM rows as the 16-bit values dptm_convert_rows makes (uint16 [n][1280], half
+ * the memory and half the host reads of fp32 rows): the handle must be in the matching one-operand mode
+ * (DPTM_PREC_BF16 / DPTM_PREC_F16, else DPTM_EINVAL).  Results are bit-identical to dptm_score on the fp32 rows the
+ * values were converted from for calls of more than 512 sites (smaller calls of dptm_score take fp32 dense kernels).
+ * No counterpart in the reference (Keras feeds fp32, predict.py:598-599). */
+int dptm_score_rows16(dptm_handle* h, const uint8_t* tok21, const uint8_t* tok33, const uint8_t* tok51,
+                      const float* strct, const uint16_t* esm16, int64_t n, float* out);
+
 /* Blocks until everything enqueued on the handle's own stream has finished. */
 int dptm_sync(dptm_handle* h);
 

@@ -125,6 +125,18 @@ def test_host_pipeline_sends_half_rows_and_scores_alike(model, mode):
     sc.sync()
     assert np.isfinite(p).all() and np.array_equal(p, out.cpu().numpy())
     del d, out
+    # a caller that keeps its rows as 16-bit values (dptm_convert_rows) hands them over as they are: same probabilities,
+    # for the pipelined call and for a one-pass call of more than 512 sites
+    from deepptmpred_amd import _native
+    x16 = _native.convert_rows(x[4], mode)
+    assert np.array_equal(sc.score_rows16(x[0], x[1], x[2], x[3], x16), p)
+    k = 700
+    assert np.array_equal(sc.score_rows16(x[0][:k], x[1][:k], x[2][:k], x[3][:k], np.ascontiguousarray(x16[:k])),
+                          sc.score(x[0][:k], x[1][:k], x[2][:k], x[3][:k], np.ascontiguousarray(x[4][:k])))
+    sc.set_precision("f32")
+    with pytest.raises(ValueError):
+        sc.score_rows16(x[0][:k], x[1][:k], x[2][:k], x[3][:k], np.ascontiguousarray(x16[:k]))      # fp32 mode has no use for them
+    sc.set_precision(mode)
     # many proteins per call: 40,000 sites of 200 proteins, rows gathered (and converted) by the host, against the
     # device-resident form of the same call (tables resident as fp32, rows gathered inside the ESM layer)
     from deepptmpred_amd.model import encode_sequence

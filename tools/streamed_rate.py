@@ -17,3 +17,12 @@ for mode in modes:
         t = time.perf_counter(); p = m.predict(x); best = min(best, time.perf_counter() - t)
     assert np.isfinite(p).all()
     print("threads", os.environ.get("DPTM_HOST_THREADS", "default"), mode, "%.3e sites/s" % (n / best), "%.1f GB/s of fp32 input" % (n * 5261 / best / 1e9))
+    if mode in ("bf16", "f16"):      # the caller keeps its ESM rows as 16-bit values (dptm_score_rows16)
+        from deepptmpred_amd import _native
+        x16 = _native.convert_rows(x[4], mode)
+        q = m.scorer.score_rows16(x[0], x[1], x[2], x[3], x16)
+        assert np.array_equal(p, q)
+        best = 1e9
+        for _ in range(3):
+            t = time.perf_counter(); q = m.scorer.score_rows16(x[0], x[1], x[2], x[3], x16); best = min(best, time.perf_counter() - t)
+        print("threads", os.environ.get("DPTM_HOST_THREADS", "default"), mode, "rows16 %.3e sites/s" % (n / best), "%.1f GB/s of 16-bit input" % (n * (2560 + 141) / best / 1e9))
