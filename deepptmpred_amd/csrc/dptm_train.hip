@@ -147,7 +147,8 @@ struct dptm_trainer {
     struct Scratch {
         f32x4_tr *dx1 = nullptr, *dz1 = nullptr;   // chain-tiled gradients handed from one backward kernel to the next
         float* part = nullptr;            // partial parameter gradients of the fused backward kernel, one slab per workgroup
-        float* row_part = nullptr;        // the same for the row-wise launches of a large batch: [2 blocks][kRowMaxParts][kRowPartStride]
+        float* row_part = nullptr;        // the same for the row-wise launches of a large batch: [2 blocks][row_parts][kRowPartStride]
+        size_t row_parts = 0;             // (none when max_batch never reaches the eight-wavefront tiles)
     };
     Scratch sc[4];                        // [0..2] sequence branches, [3] per-site layers (BatchNorm sums only)
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
@@ -195,6 +196,15 @@ namespace {
 const int kW[3] = {21, 33, 51};
 constexpr int kBnLayers = 10;   // 2 per sequence branch + struct, ESM, two trunk layers
 
+// workgroups of the row-wise backward launches that a batch of up to B sites can start: none unless the batch reaches
+// the eight-wavefront tiles (the only ones that take the five-launch form), two 128-row tiles per 256-row tile
+size_t row_parts_for(int64_t B, int wlen) {
+    const TileCfg tc = t_tile_cfg(B, wlen);
+    if (tc.NW != 8) return 0;
+    const int64_t tiles = 2 * tc.ntiles;
+    return (size_t)(tiles < kRowMaxParts ? tiles : kRowMaxParts);
+}
+
 int alloc_acts(dptm_trainer* t) {
     const int64_t B = t->max_batch;
     Arena& A = t->arena;
@@ -233,8 +243,9 @@ int alloc_acts(dptm_trainer* t) {
         if (b == 3) break;
         const size_t RP = (size_t)t_tile_rows_max(B, kW[b]);
         float *d1 = nullptr, *d2 = nullptr;
-        ok &= need(d1, RP * 64) && need(d2, RP * 64) && need(s.part, (size_t)kTbMaxParts * kTbPartStride) &&
-              need(s.row_part, (size_t)2 * kRowMaxParts * kRowPartStride);
+        ok &= need(d1, RP * 64) && need(d2, RP * 64) && need(s.part, (size_t)kTbMaxParts * kTbPartStride);
+        s.row_parts = row_parts_for(B, kW[b]);
+        if (s.row_parts) ok &= need(s.row_part, 2 * s.row_parts * kRowPartStride);
         s.dx1 = reinterpret_cast<f32x4_tr*>(d1);
         s.dz1 = reinterpret_cast<f32x4_tr*>(d2);
     }
@@ -250,7 +261,7 @@ size_t arena_bytes(int64_t B) {
         f += RP * 64 * 3;                                           // conv block activations
         f += 2 * (RP * 64 * 6 + RP * 8 + RP * 4) + RP * 4;          // saved TransformerBlock activations, pooling
         f += RP * 64 * 2 + (size_t)kTbMaxParts * kTbPartStride;     // gradient hand-over, partial gradients
-        f += (size_t)2 * kRowMaxParts * kRowPartStride;             // partial gradients of the row-wise launches
+        f += 2 * row_parts_for(B, kW[b]) * kRowPartStride;          // partial gradients of the row-wise launches
     }
     f += (size_t)B * (128 * 2 + 512 * 3 + 256 + 576 + 512 * 3 + 256 * 3 + 2);
     f += (4 + 3 * 10) * 1024 + 64 + (size_t)B * (576 + 1024 + 512 + 128);
@@ -497,6 +508,7 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
         f.gout = nullptr;
         f.dtmp = c.s->dz1;
         f.row_part = c.s->row_part;
+        f.row_parts = (int)c.s->row_parts;
         f.queues = reinterpret_cast<unsigned*>(t->d_loss + 32) + 9 + b * 5;
         TbGrads g;
         for (int i = 0; i < 2; ++i) {

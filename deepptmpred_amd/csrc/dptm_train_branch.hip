@@ -1100,7 +1100,7 @@ static hipError_t launch_bwd_split(const TbBwdArgs& a, const TbGrads& g, int gri
     if (e != hipSuccess) return e;
     const int NWf = 8;
     const int64_t nblocks = a.ntiles * NWf, row_tiles = (nblocks + 3) / 4;
-    const int row_grid = (int)(row_tiles < kRowMaxParts ? row_tiles : kRowMaxParts);
+    const int row_grid = (int)(row_tiles < a.row_parts ? row_tiles : a.row_parts);
     f32x4_tr* const Da = a.dx1;
     f32x4_tr* const Db = a.dtmp;
     auto queue = [&](int k, int64_t tiles, int launch_grid) { return tiles > launch_grid ? a.queues + k : nullptr; };
@@ -1119,7 +1119,7 @@ static hipError_t launch_bwd_split(const TbBwdArgs& a, const TbGrads& g, int gri
         r.inv = a.sv[blk].inv;
         r.din = Da;
         r.dout = Db;
-        r.part = a.row_part + (size_t)blk * kRowMaxParts * kRowPartStride;
+        r.part = a.row_part + (size_t)blk * a.row_parts * kRowPartStride;
         r.queue = queue(blk == 1 ? 1 : 3, row_tiles, row_grid);
         r.n_sites = a.n_sites;
         r.S = a.S;
@@ -1174,7 +1174,7 @@ static hipError_t launch_bwd_split(const TbBwdArgs& a, const TbGrads& g, int gri
         vec(g.ln2g[b], kRG2); vec(g.ln2b[b], kRB2); vec(g.b2[b], kRFb2);
         for (int c = 0; c < 4; ++c) vec(g.b1[b] + 64 * c, kRFb1 + c);
         vec(g.ln1g[b], kRG1); vec(g.ln1b[b], kRB1);
-        e = t_reduce_parts(a.row_part + (size_t)b * kRowMaxParts * kRowPartStride, row_grid, ut, vt, st, kRowPartStride);
+        e = t_reduce_parts(a.row_part + (size_t)b * a.row_parts * kRowPartStride, row_grid, ut, vt, st, kRowPartStride);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -1185,7 +1185,7 @@ hipError_t t_tb_bwd(const TbBwdArgs& a, const TbGrads& g, int wlen, int NW, Part
     if (!tile_ok(wlen, a.S, NW, a.n_sites, a.ntiles)) return hipErrorInvalidValue;
     const int grid = (int)(a.ntiles < kTbMaxParts ? a.ntiles : kTbMaxParts);
     hipError_t e;
-    if (NW == 8 && !part_sums_deferred(a.ntiles) && a.row_part && a.dtmp && a.queues && split_enabled()) {
+    if (NW == 8 && a.row_parts > 0 && !part_sums_deferred(a.ntiles) && a.row_part && a.dtmp && a.queues && split_enabled()) {
         switch (wlen) {
             case 21: e = launch_bwd_split<21>(a, g, grid, st); break;
             case 33: e = launch_bwd_split<33>(a, g, grid, st); break;

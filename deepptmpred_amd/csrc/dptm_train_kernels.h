@@ -241,7 +241,8 @@ struct TbBwdArgs {
     const f32x4_tr* gin;   // part 2: d(x + attention output) of the block, from the row-wise kernel
     f32x4_tr* gout;        // part 1, part 2 with blk = 1: gradient w.r.t. the output of the block below
     f32x4_tr* dtmp;        // second hand-over array (free while the TransformerBlocks go backward)
-    float* row_part;       // [kRowMaxParts][kRowPartStride] partial gradients of the row-wise launches
+    float* row_part;       // [2 blocks][row_parts][kRowPartStride] partial gradients of the row-wise launches (may be NULL)
+    int row_parts;         // workgroups a row-wise launch may start (<= kRowMaxParts)
     unsigned* queues;      // five tile counters for the split form's launches, zero when the step starts
 };
 // Row-wise half of one TransformerBlock's backward pass (no site structure: tiles of any 128 rows).

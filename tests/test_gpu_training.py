@@ -371,7 +371,7 @@ def test_step_on_rows_of_a_resident_data_set_equals_the_step_on_the_gathered_bat
     """dptm_trainer_forward_backward_rows: gather on the device + step + loss / probabilities left at device
     addresses, against dptm_trainer_forward_backward on the same rows gathered on the host.  Same kernels on the same
     values: gradients, loss and probabilities must be equal to rounding of the float atomics (1e-5 of the largest
-    gradient).  Second call with fewer rows; an index beyond the data set is clamped to its last row."""
+    gradient, 2e-5 on a probability).  Second call with fewer rows; an index beyond the data set is clamped to its last row."""
     import torch
     n_data = 300
     w = spec.synthetic_weights(9)
@@ -402,8 +402,8 @@ def test_step_on_rows_of_a_resident_data_set_equals_the_step_on_the_gathered_bat
                                    lg.data_ptr(), n, o)
         torch.cuda.synchronize()
         g_ref = tr.get_grads()
-        assert abs(loss - l_rows) < 1e-6 * max(1.0, abs(loss)), (loss, l_rows)
-        assert np.abs(tr.get_proba(n) - p_rows).max() < 1e-6
+        assert abs(loss - l_rows) < 1e-5 * max(1.0, abs(loss)), (loss, l_rows)
+        assert np.abs(tr.get_proba(n) - p_rows).max() < 2e-5      # (column sums by float atomics: two runs differ in the last bits)
         assert np.abs(g_rows - g_ref).max() < 1e-5 * np.abs(g_ref).max()
     # the outputs are optional
     tr.forward_backward_rows(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
