@@ -413,3 +413,37 @@ def test_step_on_rows_of_a_resident_data_set_equals_the_step_on_the_gathered_bat
         tr.forward_backward_rows(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
                                  lab.data_ptr(), n_data, rows_dev.data_ptr(), 129, o)       # beyond max_batch
     tr.close()
+
+
+def test_gradients_of_a_repeated_batch_equal_those_of_one_period():
+    """Size-independent property at the large-batch sizes of the bench (8,192 and 16,384 sites per step): with dropout
+    off, a batch made of k copies of a period has the period's loss and gradients -- the class weights N / (2 N_pos),
+    the mean over N * 2, every BatchNorm's batch statistics and the l2 terms are the same.  The period (4,096 sites) sits
+    next to the 4,100 sites checked against the autograd oracle above; the copies run through more rounds of tiles per
+    workgroup, the tile counters and the five-launch backward pass."""
+    import torch
+    period = 4096
+    rates = (0.0, 0.0, 0.0, 0.0)
+    w = spec.synthetic_weights(13)
+    x = spec.synthetic_inputs(period, 41)
+    y = (np.random.default_rng(12).random(period) < 0.1).astype(np.int64)
+    tr = _native.Trainer(spec.pack_blob(w), max_batch=4 * period)
+    results = []
+    for k in (1, 2, 4):
+        xs = [np.concatenate([a] * k) for a in x]
+        ys = np.concatenate([y] * k)
+        d, lab = _device_batch(xs, ys)
+        loss = tr.forward_backward(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+                                   lab.data_ptr(), k * period, _opts(3, rates, ys))
+        torch.cuda.synchronize()
+        results.append((loss, tr.get_grads()))
+        del d, lab
+    (l1, g1) = results[0]
+    scale = np.abs(g1).max()
+    assert scale > 0 and np.isfinite(g1).all()
+    for (lk, gk), k in zip(results[1:], (2, 4)):
+        assert abs(lk - l1) < 2e-5 * max(1.0, abs(l1)), (k, lk, l1)
+        err = np.abs(gk - g1).max() / scale
+        print("copies", k, "max gradient difference / largest gradient %.2e" % err)
+        assert err < 2e-4, (k, err)
+    tr.close()
