@@ -424,6 +424,30 @@ BnFwd bn2_fwd(const Ctx& c, int b, int64_t B) {
                  c.w(p.bn2.beta), c.g(p.bn2.mean), c.g(p.bn2.var)};
 }
 
+// BN2 + shortcut add, both TransformerBlocks and the attention pooling (model.py:138-141, 172-182): arguments of branch b
+TbFwdArgs tb_fwd_args(const Ctx& c, int b, const ConvArgs& cf, int64_t B, const unsigned* seed, const Rates& rt, const TileCfg& tc) {
+    dptm_trainer* t = c.t;
+    BranchAct& a = t->ba[b];
+    TbFwdArgs f;
+    f.P = cf.P;
+    f.cs = a.cs;
+    f.bn2 = bn2_fwd(c, b, B);
+    f.sv[0] = a.sv[0];
+    f.sv[1] = a.sv[1];
+    f.pool = a.pool;
+    f.out = t->concat;
+    f.ldo = kConcat;
+    f.col_off = b * 64;
+    f.n_sites = B;
+    f.S = tc.S;
+    f.ntiles = tc.ntiles;
+    f.step = seed;
+    f.stream_base = (unsigned)(b * 8 + 2);
+    f.thr = dropout_threshold(rt.tb);
+    f.scale = rt.tb > 0.f ? 1.0f / (1.0f - rt.tb) : 1.0f;
+    return f;
+}
+
 // One sequence branch forward (model.py:157-182) in three launches; the cuts sit where a BatchNorm needs the
 // statistics of the whole batch (and, with synchronised BatchNorm, of all replicas).  Launches first..last of the three
 // (synchronised BatchNorm runs the branches stage by stage and sums the three branches' column sums in between).
@@ -443,28 +467,70 @@ int branch_fwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
         T_TRY(t_conv_b_fwd(cf, wl, tc.NW, c.st));
     }
     if (first <= 2 && last >= 2) {
-        // BN2 + shortcut add, both TransformerBlocks and the attention pooling (model.py:138-141, 172-182)
-        TbFwdArgs f;
-        f.P = cf.P;
-        f.cs = a.cs;
-        f.bn2 = bn2_fwd(c, b, B);
-        f.sv[0] = a.sv[0];
-        f.sv[1] = a.sv[1];
-        f.pool = a.pool;
-        f.out = t->concat;
-        f.ldo = kConcat;
-        f.col_off = b * 64;
-        f.n_sites = B;
-        f.S = tc.S;
-        f.ntiles = tc.ntiles;
-        f.step = seed;
-        f.stream_base = (unsigned)(b * 8 + 2);
-        f.thr = dropout_threshold(rt.tb);
-        f.scale = rt.tb > 0.f ? 1.0f / (1.0f - rt.tb) : 1.0f;
+        const TbFwdArgs f = tb_fwd_args(c, b, cf, B, seed, rt, tc);
         ProfScope ps(c, b * 6 + 2);
         T_TRY(t_tb_fwd(f, wl, tc.NW, c.st));
     }
     return DPTM_OK;
+}
+
+// pooling and both TransformerBlocks backward: d(concat columns of this branch) -> d(x1), BN2 column sums
+TbBwdArgs tb_bwd_args(const Ctx& c, int b, const ConvArgs& cf, int64_t B, const unsigned* seed, const Rates& rt, const TileCfg& tc) {
+    dptm_trainer* t = c.t;
+    BranchAct& a = t->ba[b];
+    const BranchP& p = t->pm.br[b];
+    TbBwdArgs f;
+    f.P = cf.P;
+    f.PT = cf.PT;
+    f.cs = a.cs;
+    f.bn2 = bn2_fwd(c, b, B);
+    f.bn2_sums = t->bn_slots + (size_t)(kBnLayers + p.bn2.slot) * 1024;
+    f.sv[0] = a.sv[0];
+    f.sv[1] = a.sv[1];
+    f.pool = a.pool;
+    f.dout = t->dconcat;
+    f.ldd = kConcat;
+    f.col_off = b * 64;
+    f.dx1 = c.s->dx1;
+    f.part = c.s->part;
+    f.queue = tile_queue(t, b, 0, tc.ntiles);
+    f.n_sites = B;
+    f.S = tc.S;
+    f.ntiles = tc.ntiles;
+    f.step = seed;
+    f.stream_base = (unsigned)(b * 8 + 2);
+    f.thr = dropout_threshold(rt.tb);
+    f.scale = rt.tb > 0.f ? 1.0f / (1.0f - rt.tb) : 1.0f;
+    // the split form of large batches: second hand-over array (idle until the convolutions go backward), partial
+    // buffers of the row-wise launches, five more tile counters behind the nine of tile_queue
+    f.blk = 0;
+    f.gin = nullptr;
+    f.gout = nullptr;
+    f.dtmp = c.s->dz1;
+    f.row_part = c.s->row_part;
+    f.row_parts = (int)c.s->row_parts;
+    f.queues = reinterpret_cast<unsigned*>(t->d_loss + 32) + 9 + b * 5;
+    return f;
+}
+
+TbGrads tb_grads(const Ctx& c, int b) {
+    const BranchP& p = c.t->pm.br[b];
+    TbGrads g;
+    for (int i = 0; i < 2; ++i) {
+        const TbP& w = p.tb[i];
+        g.wq[i] = c.g(w.wq); g.bq[i] = c.g(w.bq); g.wk[i] = c.g(w.wk); g.bk[i] = c.g(w.bk);
+        g.wv[i] = c.g(w.wv); g.bv[i] = c.g(w.bv); g.wo[i] = c.g(w.wo); g.bo[i] = c.g(w.bo);
+        g.w1[i] = c.g(w.f1k); g.b1[i] = c.g(w.f1b); g.w2[i] = c.g(w.f2k); g.b2[i] = c.g(w.f2b);
+        g.ln1g[i] = c.g(w.ln1g); g.ln1b[i] = c.g(w.ln1b); g.ln2g[i] = c.g(w.ln2g); g.ln2b[i] = c.g(w.ln2b);
+    }
+    g.poolw = c.g(p.poolk);
+    g.poolb = c.g(p.poolb);
+    return g;
+}
+
+ConvGrads conv_grads(const Ctx& c, int b) {
+    const BranchP& p = c.t->pm.br[b];
+    return ConvGrads{c.g(p.emb), c.g(p.pos), c.g(p.sck), c.g(p.scb), c.g(p.c3ak), c.g(p.c3ab), c.g(p.c3bk), c.g(p.c3bb)};
 }
 
 // d(concat)[:, b*64 .. +64]  ->  all parameter gradients of branch b, in three launches (+ the partial-sum kernels):
@@ -478,52 +544,12 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
     const TileCfg tc = t_tile_cfg(B, wl);
     const ConvArgs cf = conv_args(c, b, tok, B, seed, rt, tc);
     if (first <= 0 && last >= 0) {
-        // pooling and both TransformerBlocks backward: d(concat columns of this branch) -> d(x1), BN2 column sums
-        TbBwdArgs f;
-        f.P = cf.P;
-        f.PT = cf.PT;
-        f.cs = a.cs;
-        f.bn2 = bn2_fwd(c, b, B);
-        f.bn2_sums = t->bn_slots + (size_t)(kBnLayers + p.bn2.slot) * 1024;
-        f.sv[0] = a.sv[0];
-        f.sv[1] = a.sv[1];
-        f.pool = a.pool;
-        f.dout = t->dconcat;
-        f.ldd = kConcat;
-        f.col_off = b * 64;
-        f.dx1 = c.s->dx1;
-        f.part = c.s->part;
-        f.queue = tile_queue(t, b, 0, tc.ntiles);
-        f.n_sites = B;
-        f.S = tc.S;
-        f.ntiles = tc.ntiles;
-        f.step = seed;
-        f.stream_base = (unsigned)(b * 8 + 2);
-        f.thr = dropout_threshold(rt.tb);
-        f.scale = rt.tb > 0.f ? 1.0f / (1.0f - rt.tb) : 1.0f;
-        // the split form of large batches: second hand-over array (idle until the convolutions go backward), partial
-        // buffers of the row-wise launches, five more tile counters behind the nine of tile_queue
-        f.blk = 0;
-        f.gin = nullptr;
-        f.gout = nullptr;
-        f.dtmp = c.s->dz1;
-        f.row_part = c.s->row_part;
-        f.row_parts = (int)c.s->row_parts;
-        f.queues = reinterpret_cast<unsigned*>(t->d_loss + 32) + 9 + b * 5;
-        TbGrads g;
-        for (int i = 0; i < 2; ++i) {
-            const TbP& w = p.tb[i];
-            g.wq[i] = c.g(w.wq); g.bq[i] = c.g(w.bq); g.wk[i] = c.g(w.wk); g.bk[i] = c.g(w.bk);
-            g.wv[i] = c.g(w.wv); g.bv[i] = c.g(w.bv); g.wo[i] = c.g(w.wo); g.bo[i] = c.g(w.bo);
-            g.w1[i] = c.g(w.f1k); g.b1[i] = c.g(w.f1b); g.w2[i] = c.g(w.f2k); g.b2[i] = c.g(w.f2b);
-            g.ln1g[i] = c.g(w.ln1g); g.ln1b[i] = c.g(w.ln1b); g.ln2g[i] = c.g(w.ln2g); g.ln2b[i] = c.g(w.ln2b);
-        }
-        g.poolw = c.g(p.poolk);
-        g.poolb = c.g(p.poolb);
+        const TbBwdArgs f = tb_bwd_args(c, b, cf, B, seed, rt, tc);
+        const TbGrads g = tb_grads(c, b);
         ProfScope ps(c, b * 6 + 3);
         T_TRY(t_tb_bwd(f, g, wl, tc.NW, plan, c.st));
     }
-    const ConvGrads cg{c.g(p.emb), c.g(p.pos), c.g(p.sck), c.g(p.scb), c.g(p.c3ak), c.g(p.c3ab), c.g(p.c3bk), c.g(p.c3bb)};
+    const ConvGrads cg = conv_grads(c, b);
     if (first <= 1 && last >= 1) {
         ProfScope ps(c, b * 6 + 4);
         T_TRY(t_conv_b_bwd(cf, cg, wl, tc.NW, plan, c.st));
@@ -892,9 +918,60 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
     // ---------------- forward.  Four lanes of work: the W=21 and W=33 branches on side streams, the W=51 branch (the
     // longest) on the step's main stream `st`, the structure / ESM layers of a small batch on a third side stream `ss`.
     // (A process has four hardware queues: a fifth concurrent stream would share one and serialise behind it.)
-    hipStream_t bstream[3] = {t->serial ? st : t->aux[0], t->serial ? st : t->aux[1], st};
+    // Batches whose tiles of all three branches are on the chip at once (up to ~540 sites) start each of the branches'
+    // six launches ONCE for all three branches (grid.y = branch) on the main stream: the step is then a chain of launches
+    // on one queue, and no hand-over between streams -- 10 to 25 us each -- sits on its critical path.  (Not under a
+    // profile, whose clocks are per branch, nor with synchronised BatchNorm, which sums between the stages.)
+    static const bool merge_allowed = [] {
+        const char* e = std::getenv("DPTM_TRAIN_MERGE");        // DPTM_TRAIN_MERGE=0: one launch per branch (A/B)
+        return !(e && e[0] == '0');
+    }();
+    bool merged3 = merge_allowed && !t->serial && !t->prof_on && !t->ar_fn;
+    const int nw3 = t_tile_cfg(B, kW[2]).NW;
+    int64_t wgs3 = 0;
+    for (int b = 0; b < 3 && merged3; ++b) {
+        const TileCfg tcb = t_tile_cfg(B, kW[b]);
+        merged3 = tcb.NW == nw3 && (nw3 == 4 || nw3 == 8) && part_sums_deferred(tcb.ntiles);
+        wgs3 += tcb.ntiles;
+    }
+    // ... while all their workgroups are on the chip at once (measured: 512 sites 1.35 -> 1.18 ms; beyond one round of
+    // workgroups -- 768, 1,280 sites -- three streams that take turns on the CUs are the faster form again)
+    merged3 = merged3 && wgs3 <= 232;      // (a little short of the 256 CUs: the per-site lane needs some too)
+    hipStream_t bstream[3] = {t->serial || merged3 ? st : t->aux[0], t->serial || merged3 ? st : t->aux[1], st};
     hipStream_t ss = !t->serial ? t->aux[2] : st;      // per-site layers that run next to the branches
     hipStream_t side[3] = {bstream[0], bstream[1], ss};
+    auto branches3 = [&](bool forward) -> int {
+        ConvArgs cf[3];
+        for (int b = 0; b < 3; ++b) {
+            Ctx cb{t, st, t->W, t->G, &t->sc[b]};
+            cf[b] = conv_args(cb, b, tok[b], B, seed, rt, t_tile_cfg(B, kW[b]));
+        }
+        if (forward) {
+            TbFwdArgs f[3];
+            for (int b = 0; b < 3; ++b) {
+                Ctx cb{t, st, t->W, t->G, &t->sc[b]};
+                f[b] = tb_fwd_args(cb, b, cf[b], B, seed, rt, t_tile_cfg(B, kW[b]));
+            }
+            T_TRY(t_conv_a_fwd3(cf, nw3, st));
+            T_TRY(t_conv_b_fwd3(cf, nw3, st));
+            T_TRY(t_tb_fwd3(f, nw3, st));
+            return DPTM_OK;
+        }
+        TbBwdArgs f[3];
+        TbGrads g[3];
+        ConvGrads cg[3];
+        PartPlan plans[3];
+        for (int b = 0; b < 3; ++b) {
+            Ctx cb{t, st, t->W, t->G, &t->sc[b]};
+            f[b] = tb_bwd_args(cb, b, cf[b], B, seed, rt, t_tile_cfg(B, kW[b]));
+            g[b] = tb_grads(cb, b);
+            cg[b] = conv_grads(cb, b);
+        }
+        T_TRY(t_tb_bwd3(f, g, nw3, plans, st));
+        T_TRY(t_conv_b_bwd3(cf, cg, nw3, plans, st));
+        T_TRY(t_conv_a_bwd3(cf, cg, nw3, plans, st));
+        return DPTM_OK;
+    };
     // the longest branch first: its launches are then the first the host hands to the device
     // Synchronised BatchNorm: the three branches advance stage by stage, and between two stages the main stream sums
     // the column sums all three just produced over the replicas in ONE collective (their slots are contiguous):
@@ -925,6 +1002,7 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
         return DPTM_OK;
     };
     auto branches = [&](bool forward, int first, int last) -> int {
+        if (merged3) return last == 2 ? branches3(forward) : DPTM_OK;     // (all three go out with the call that holds W = 51)
         PartPlan plans[3];
         const bool staged = t->ar_fn != nullptr && first == 0 && last == 2;
         for (int stage = 0; stage < (staged ? 3 : 1); ++stage) {

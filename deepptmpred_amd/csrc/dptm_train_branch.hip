@@ -153,13 +153,18 @@ int64_t t_tile_rows_max(int64_t max_sites, int wlen) {
 
 // What the forward kernel keeps for the backward pass is written once and read once, milliseconds apart: both
 // sides carry the non-temporal hint, so that the arrays do not displace the weight images from the caches.
+#ifdef DPTM_EXP_PLAIN_KEEP
+__device__ __forceinline__ void keep_store(f32x4* p, const f32x4& v) { *p = v; }
+__device__ __forceinline__ f32x4 keep_load(const f32x4* p) { return *p; }
+#else
 __device__ __forceinline__ void keep_store(f32x4* p, const f32x4& v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ f32x4 keep_load(const f32x4* p) { return __builtin_nontemporal_load(p); }
+#endif
 
 // ------------------------------------------------------------------------------------ forward
 
 template <int W>
-__global__ __launch_bounds__(512) void tb_fwd_kernel(TbFwdArgs p) {
+__device__ __forceinline__ void tb_fwd_body(const TbFwdArgs& p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int NW = blockDim.x >> 6, rows_tile = NW * 32;
     float* bufA = lds;
@@ -438,7 +443,7 @@ static_assert(kSPoolB < kTbVecs, "vector slots");
 // MODE 1 = the pooling alone, MODE 2 = the attention half of block p.blk (output projection, attention, Q / K / V); the
 // row-wise half of a block runs in tb_row_bwd_kernel between them.
 template <int W, int MAXT, int MODE>
-__global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
+__device__ __forceinline__ void tb_bwd_body(const TbBwdArgs& p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int NW = blockDim.x >> 6, rows_tile = NW * 32;
     const int img = img_floats(NW);                  // room for a row-major [rows][68] or a transposed [64][rows + 4] image
@@ -841,6 +846,38 @@ __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) {
 #undef AT1
 }
 
+// ------------------------------------------------------------------------------------ kernels
+
+template <int W>
+__global__ __launch_bounds__(512) void tb_fwd_kernel(TbFwdArgs p) { tb_fwd_body<W>(p); }
+template <int W, int MAXT, int MODE>
+__global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) { tb_bwd_body<W, MAXT, MODE>(p); }
+
+// The three branches' launch as ONE (grid.y = branch; four-wavefront tiles, a tile per workgroup): see conv_a_fwd3_kernel
+struct TbFwdArgs3 { TbFwdArgs a[3]; };
+struct TbBwdArgs3 { TbBwdArgs a[3]; };
+// (grid.y = 0 is the longest branch, W = 51: its workgroups are handed out first; MAXT: 256 for four-wavefront tiles, 512 for eight)
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void tb_fwd3_kernel(TbFwdArgs3 p) {
+    if (blockIdx.y == 2) {
+        if ((int64_t)blockIdx.x < p.a[0].ntiles) tb_fwd_body<21>(p.a[0]);
+    } else if (blockIdx.y == 1) {
+        if ((int64_t)blockIdx.x < p.a[1].ntiles) tb_fwd_body<33>(p.a[1]);
+    } else {
+        if ((int64_t)blockIdx.x < p.a[2].ntiles) tb_fwd_body<51>(p.a[2]);
+    }
+}
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void tb_bwd3_kernel(TbBwdArgs3 p) {
+    if (blockIdx.y == 2) {
+        if ((int64_t)blockIdx.x < p.a[0].ntiles) tb_bwd_body<21, MAXT, 0>(p.a[0]);
+    } else if (blockIdx.y == 1) {
+        if ((int64_t)blockIdx.x < p.a[1].ntiles) tb_bwd_body<33, MAXT, 0>(p.a[1]);
+    } else {
+        if ((int64_t)blockIdx.x < p.a[2].ntiles) tb_bwd_body<51, MAXT, 0>(p.a[2]);
+    }
+}
+
 // ------------------------------------------------------------------------------------ row-wise half, large batches
 
 // index of the vectors in a workgroup's partial buffer (behind its kRowUnits units)
@@ -995,8 +1032,8 @@ static size_t row_lds() { return ((size_t)2 * 64 * kTsRow + kRowVecs * 64 + 64) 
 // elements each: thread o of a unit is element [block o>>10][register (o>>6)&15][lane o&63]), then the vectors in
 // chunks of 256 floats; grid.y = part group: group y adds parts y, y + gridDim.y, ... and its sum joins the
 // destination through one atomic per element (the destinations start from the step's zeroed gradient buffer).
-__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int nparts, PartUnits ut, PartVecs vt,
-                                                           int stride) {
+__device__ __forceinline__ void reduce_parts_body(const float* __restrict__ part, int nparts, const PartUnits& ut, const PartVecs& vt,
+                                                  int stride) {
     const int item = blockIdx.x;
     const float* src;
     float* dst;
@@ -1027,6 +1064,26 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
     }
     if (pi < nparts) a0 += src[(size_t)pi * stride];
     atomicAdd(dst, a0 + a1);
+}
+
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int nparts, PartUnits ut, PartVecs vt,
+                                                           int stride) {
+    reduce_parts_body(part, nparts, ut, vt, stride);
+}
+// the partial buffers of the three branches in one launch: grid.z = branch
+struct ReduceParts3 {
+    const float* part[3];
+    int nparts[3];
+    PartUnits ut[3];
+    PartVecs vt[3];
+};
+__global__ __launch_bounds__(256) void reduce_parts3_kernel(ReduceParts3 r) {
+    if (blockIdx.z == 0)
+        reduce_parts_body(r.part[0], r.nparts[0], r.ut[0], r.vt[0], kTbPartStride);
+    else if (blockIdx.z == 1)
+        reduce_parts_body(r.part[1], r.nparts[1], r.ut[1], r.vt[1], kTbPartStride);
+    else
+        reduce_parts_body(r.part[2], r.nparts[2], r.ut[2], r.vt[2], kTbPartStride);
 }
 
 hipError_t t_reduce_parts(const float* part, int nparts, const PartUnits& u, const PartVecs& v, hipStream_t st, int part_stride) {
@@ -1180,28 +1237,9 @@ static hipError_t launch_bwd_split(const TbBwdArgs& a, const TbGrads& g, int gri
     return hipSuccess;
 }
 
-hipError_t t_tb_bwd(const TbBwdArgs& a, const TbGrads& g, int wlen, int NW, PartPlan* plan, hipStream_t st) {
-    if (a.n_sites == 0) return hipSuccess;
-    if (!tile_ok(wlen, a.S, NW, a.n_sites, a.ntiles)) return hipErrorInvalidValue;
-    const int grid = (int)(a.ntiles < kTbMaxParts ? a.ntiles : kTbMaxParts);
-    hipError_t e;
-    if (NW == 8 && a.row_parts > 0 && !part_sums_deferred(a.ntiles) && a.row_part && a.dtmp && a.queues && split_enabled()) {
-        switch (wlen) {
-            case 21: e = launch_bwd_split<21>(a, g, grid, st); break;
-            case 33: e = launch_bwd_split<33>(a, g, grid, st); break;
-            default: e = launch_bwd_split<51>(a, g, grid, st); break;
-        }
-        plan->units.n = 0;
-        plan->vecs.n = 0;
-        return e;
-    }
-    switch (wlen) {
-        case 21: e = launch_bwd<21>(a, NW, grid, st); break;
-        case 33: e = launch_bwd<33>(a, NW, grid, st); break;
-        default: e = launch_bwd<51>(a, NW, grid, st); break;
-    }
-    if (e != hipSuccess) return e;
-    // units 0 .. 23 and vectors 0 .. 29 of the plan (the convolution kernels append theirs)
+// units 0 .. 23 and vectors 0 .. 29 of a branch's plan: what the TransformerBlock / pooling backward launch leaves in a
+// workgroup's partial buffer (the convolution kernels append theirs)
+static void tb_bwd_plan(const TbGrads& g, PartPlan* plan) {
     PartUnits& ut = plan->units;
     PartVecs& vt = plan->vecs;
     ut = PartUnits();
@@ -1234,6 +1272,32 @@ hipError_t t_tb_bwd(const TbBwdArgs& a, const TbGrads& g, int wlen, int NW, Part
     }
     vt.dst[kSPoolW] = g.poolw;
     vt.dst[kSPoolB] = g.poolb; vt.len[kSPoolB] = 1;
+}
+
+hipError_t t_tb_bwd(const TbBwdArgs& a, const TbGrads& g, int wlen, int NW, PartPlan* plan, hipStream_t st) {
+    if (a.n_sites == 0) return hipSuccess;
+    if (!tile_ok(wlen, a.S, NW, a.n_sites, a.ntiles)) return hipErrorInvalidValue;
+    const int grid = (int)(a.ntiles < kTbMaxParts ? a.ntiles : kTbMaxParts);
+    hipError_t e;
+    if (NW == 8 && a.row_parts > 0 && !part_sums_deferred(a.ntiles) && a.row_part && a.dtmp && a.queues && split_enabled()) {
+        switch (wlen) {
+            case 21: e = launch_bwd_split<21>(a, g, grid, st); break;
+            case 33: e = launch_bwd_split<33>(a, g, grid, st); break;
+            default: e = launch_bwd_split<51>(a, g, grid, st); break;
+        }
+        plan->units.n = 0;
+        plan->vecs.n = 0;
+        return e;
+    }
+    switch (wlen) {
+        case 21: e = launch_bwd<21>(a, NW, grid, st); break;
+        case 33: e = launch_bwd<33>(a, NW, grid, st); break;
+        default: e = launch_bwd<51>(a, NW, grid, st); break;
+    }
+    if (e != hipSuccess) return e;
+    tb_bwd_plan(g, plan);
+    PartUnits& ut = plan->units;
+    PartVecs& vt = plan->vecs;
     if (part_sums_deferred(a.ntiles)) return hipSuccess;
     e = t_reduce_parts(a.part, grid, ut, vt, st);
     ut.n = 0;
@@ -1241,6 +1305,78 @@ hipError_t t_tb_bwd(const TbBwdArgs& a, const TbGrads& g, int wlen, int NW, Part
     return e;
 }
 
+// ---- the three branches in one launch (tb_fwd3_kernel, tb_bwd3_kernel, reduce_parts3_kernel)
+
+static_assert(sizeof(ReduceParts3) <= 4000 && sizeof(TbBwdArgs3) <= 4000 && sizeof(TbFwdArgs3) <= 4000, "kernel argument blocks");
+
+template <typename A>
+static bool tb3_ok(const A (&a)[3], int NW) {
+    const int wl[3] = {21, 33, 51};
+    if (NW != 4 && NW != 8) return false;
+    for (int b = 0; b < 3; ++b)
+        if (a[b].n_sites < 1 || a[b].ntiles > kTbMaxParts || !tile_ok(wl[b], a[b].S, NW, a[b].n_sites, a[b].ntiles)) return false;
+    return true;
+}
+
+hipError_t t_tb_fwd3(const TbFwdArgs (&a)[3], int NW, hipStream_t st) {
+    static bool d4[64] = {}, d8[64] = {};
+    if (!tb3_ok(a, NW)) return hipErrorInvalidValue;
+    hipError_t e = NW == 4 ? lds_opt_in(&tb_fwd3_kernel<256>, d4, fwd_lds(4)) : lds_opt_in(&tb_fwd3_kernel<512>, d8, fwd_lds(8));
+    if (e != hipSuccess) return e;
+    TbFwdArgs3 p;
+    int64_t gx = 1;
+    for (int b = 0; b < 3; ++b) {
+        p.a[b] = a[b];
+        gx = a[b].ntiles > gx ? a[b].ntiles : gx;
+    }
+    if (NW == 4)
+        hipLaunchKernelGGL(tb_fwd3_kernel<256>, dim3((unsigned)gx, 3), dim3(256), fwd_lds(4), st, p);
+    else
+        hipLaunchKernelGGL(tb_fwd3_kernel<512>, dim3((unsigned)gx, 3), dim3(512), fwd_lds(8), st, p);
+    return hipGetLastError();
+}
+
+hipError_t t_tb_bwd3(const TbBwdArgs (&a)[3], const TbGrads (&g)[3], int NW, PartPlan (&plan)[3], hipStream_t st) {
+    static bool d4[64] = {}, d8[64] = {};
+    if (!tb3_ok(a, NW)) return hipErrorInvalidValue;
+    hipError_t e = NW == 4 ? lds_opt_in(&tb_bwd3_kernel<256>, d4, bwd_lds(4)) : lds_opt_in(&tb_bwd3_kernel<512>, d8, bwd_lds(8));
+    if (e != hipSuccess) return e;
+    TbBwdArgs3 p;
+    int64_t gx = 1;
+    for (int b = 0; b < 3; ++b) {
+        p.a[b] = a[b];
+        p.a[b].queue = nullptr;        // a tile per workgroup
+        gx = a[b].ntiles > gx ? a[b].ntiles : gx;
+        tb_bwd_plan(g[b], &plan[b]);
+    }
+    if (NW == 4)
+        hipLaunchKernelGGL(tb_bwd3_kernel<256>, dim3((unsigned)gx, 3), dim3(256), bwd_lds(4), st, p);
+    else
+        hipLaunchKernelGGL(tb_bwd3_kernel<512>, dim3((unsigned)gx, 3), dim3(512), bwd_lds(8), st, p);
+    return hipGetLastError();
+}
+
+hipError_t t_reduce_parts3(const float* const (&part)[3], const int (&nparts)[3], const PartPlan (&plan)[3], hipStream_t st) {
+    ReduceParts3 r;
+    int items = 0, most = 0;
+    for (int b = 0; b < 3; ++b) {
+        r.part[b] = part[b];
+        r.nparts[b] = nparts[b];
+        r.ut[b] = plan[b].units;
+        r.vt[b] = plan[b].vecs;
+        int n = plan[b].units.n * 16;
+        for (int i = 0; i < plan[b].vecs.n; ++i) n += (plan[b].vecs.len[i] + 255) / 256;
+        items = n > items ? n : items;
+        most = nparts[b] > most ? nparts[b] : most;
+    }
+    if (items == 0 || most == 0) return hipSuccess;
+    int groups = (most + 15) / 16;
+    groups = groups > 8 ? 8 : groups;
+    hipLaunchKernelGGL(reduce_parts3_kernel, dim3((unsigned)items, (unsigned)groups, 3), dim3(256), 0, st, r);
+    return hipGetLastError();
+}
+
 }  // namespace dptm
+
 
 PH_DEFINE_READER(dptm_debug_phase_cycles_train)

@@ -184,7 +184,7 @@ constexpr int kConvLdsExtra = kXreg + 768;   // exchange buffer, coefficient vec
 // ------------------------------------------------------------------------------------ forward
 
 template <int W>
-__global__ __launch_bounds__(512) void conv_a_fwd_kernel(ConvArgs p) {
+__device__ __forceinline__ void conv_a_fwd_body(const ConvArgs& p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int NW = blockDim.x >> 6, rows_tile = NW * 32;
     float* bufA = lds;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(512) void conv_a_fwd_kernel(ConvArgs p) {
 }
 
 template <int W>
-__global__ __launch_bounds__(512) void conv_b_fwd_kernel(ConvArgs p) {
+__device__ __forceinline__ void conv_b_fwd_body(const ConvArgs& p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int NW = blockDim.x >> 6, rows_tile = NW * 32;
     float* bufA = lds;
@@ -338,7 +338,7 @@ static_assert(kCbVec + 64 <= kCbFloats && kCaPos + kMaxW * 64 <= kCaFloats && kM
 
 // SHORT: the instance for tiles of fewer than eight wavefronts (small batches), see dw_unit
 template <int W, bool SHORT>
-__global__ __launch_bounds__(512) void conv_b_bwd_kernel(ConvArgs p) {
+__device__ __forceinline__ void conv_b_bwd_body(const ConvArgs& p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int NW = blockDim.x >> 6, rows_tile = NW * 32;
     float* bufA = lds;
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(512) void conv_b_bwd_kernel(ConvArgs p) {
 }
 
 template <int W, bool SHORT>
-__global__ __launch_bounds__(512) void conv_a_bwd_kernel(ConvArgs p) {
+__device__ __forceinline__ void conv_a_bwd_body(const ConvArgs& p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int NW = blockDim.x >> 6, rows_tile = NW * 32;
     float* bufA = lds;
@@ -557,6 +557,42 @@ __global__ __launch_bounds__(512) void conv_a_bwd_kernel(ConvArgs p) {
     for (int i = tid; i < 128; i += blockDim.x) part[kCaVec + i] = vacc[i];
 }
 
+// ------------------------------------------------------------------------------------ kernels
+
+template <int W>
+__global__ __launch_bounds__(512) void conv_a_fwd_kernel(ConvArgs p) { conv_a_fwd_body<W>(p); }
+template <int W>
+__global__ __launch_bounds__(512) void conv_b_fwd_kernel(ConvArgs p) { conv_b_fwd_body<W>(p); }
+template <int W, bool SHORT>
+__global__ __launch_bounds__(512) void conv_b_bwd_kernel(ConvArgs p) { conv_b_bwd_body<W, SHORT>(p); }
+template <int W, bool SHORT>
+__global__ __launch_bounds__(512) void conv_a_bwd_kernel(ConvArgs p) { conv_a_bwd_body<W, SHORT>(p); }
+
+// The same launch of the three sequence branches as ONE launch, grid.y = branch (four-wavefront tiles, a tile per
+// workgroup; grid.x = the most tiles a branch has, a workgroup beyond its branch's tiles leaves at once).  A small batch's
+// step is then a chain of launches on one stream: no hand-over between streams sits on its critical path.
+// (grid.y = 0 is the longest branch, W = 51: its workgroups are handed out first)
+#define DPTM_BRANCH3(BODY21, BODY33, BODY51)                                         \
+    if (blockIdx.y == 2) {                                                           \
+        if ((int64_t)blockIdx.x < p.a[0].ntiles) BODY21(p.a[0]);                     \
+    } else if (blockIdx.y == 1) {                                                    \
+        if ((int64_t)blockIdx.x < p.a[1].ntiles) BODY33(p.a[1]);                     \
+    } else {                                                                         \
+        if ((int64_t)blockIdx.x < p.a[2].ntiles) BODY51(p.a[2]);                     \
+    }
+struct ConvArgs3 { ConvArgs a[3]; };
+// MAXT: 256 for four-wavefront tiles, 512 for eight
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void conv_a_fwd3_kernel(ConvArgs3 p) { DPTM_BRANCH3(conv_a_fwd_body<21>, conv_a_fwd_body<33>, conv_a_fwd_body<51>) }
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void conv_b_fwd3_kernel(ConvArgs3 p) { DPTM_BRANCH3(conv_b_fwd_body<21>, conv_b_fwd_body<33>, conv_b_fwd_body<51>) }
+#define DPTM_CBB(W) conv_b_bwd_body<W, MAXT == 256>
+#define DPTM_CAB(W) conv_a_bwd_body<W, MAXT == 256>
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void conv_b_bwd3_kernel(ConvArgs3 p) { DPTM_BRANCH3(DPTM_CBB(21), DPTM_CBB(33), DPTM_CBB(51)) }
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void conv_a_bwd3_kernel(ConvArgs3 p) { DPTM_BRANCH3(DPTM_CAB(21), DPTM_CAB(33), DPTM_CAB(51)) }
+
 // ------------------------------------------------------------------------------------ launchers
 
 static size_t conv_fwd_lds(int NW) { return ((size_t)2 * NW * 32 * kLdsStride + 256) * sizeof(float); }
@@ -609,12 +645,8 @@ hipError_t t_conv_b_fwd(const ConvArgs& a, int wlen, int NW, hipStream_t st) {
     return e;
 }
 
-hipError_t t_conv_b_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW, PartPlan* plan, hipStream_t st) {
-    if (a.n_sites == 0) return hipSuccess;
-    if (!tile_ok(wlen, a.S, NW, a.n_sites, a.ntiles)) return hipErrorInvalidValue;
-    hipError_t e;
-    DPTM_CONV_DISPATCH_BWD(conv_b_bwd_kernel, conv_bwd_lds(NW), conv_bwd_lds(8), kTbMaxParts)
-    if (e != hipSuccess) return e;
+// what the second / first convolution's backward launch leaves in a workgroup's partial buffer, appended to the plan
+static hipError_t conv_b_bwd_plan(const ConvGrads& g, PartPlan* plan) {
     PartUnits& ut = plan->units;
     PartVecs& vt = plan->vecs;
     if (ut.n + 3 > kPartMaxUnits || vt.n + 1 > kPartMaxVecs) return hipErrorInvalidValue;
@@ -627,6 +659,35 @@ hipError_t t_conv_b_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW,
     }
     vt.dst[vt.n] = g.c3bb; vt.off[vt.n] = kCbBase + kCbVec; vt.len[vt.n] = 64;
     ++vt.n;
+    return hipSuccess;
+}
+static hipError_t conv_a_bwd_plan(const ConvGrads& g, int wlen, PartPlan* plan) {
+    PartUnits& ut = plan->units;
+    PartVecs& vt = plan->vecs;
+    if (ut.n + 5 > kPartMaxUnits || vt.n + 3 > kPartMaxVecs) return hipErrorInvalidValue;
+    float* const unit_dst[5] = {g.c3ak, g.c3ak + 4096, g.c3ak + 2 * 4096, g.sck, g.emb};
+    for (int t = 0; t < 5; ++t) {
+        ut.dst[ut.n] = unit_dst[t];
+        ut.off[ut.n] = kCaBase + t * 4096;
+        ut.ld[ut.n] = 64;
+        ut.rows[ut.n] = t == 4 ? kCodes : 64;       // embedding table [kCodes][64]: only the unit's first kCodes rows exist
+        ++ut.n;
+    }
+    vt.dst[vt.n] = g.c3ab; vt.off[vt.n] = kCaBase + kCaVec; vt.len[vt.n] = 64; ++vt.n;
+    vt.dst[vt.n] = g.scb; vt.off[vt.n] = kCaBase + kCaVec + 64; vt.len[vt.n] = 64; ++vt.n;
+    vt.dst[vt.n] = g.pos; vt.off[vt.n] = kCaBase + kCaPos; vt.len[vt.n] = wlen * 64; ++vt.n;
+    return hipSuccess;
+}
+
+hipError_t t_conv_b_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW, PartPlan* plan, hipStream_t st) {
+    if (a.n_sites == 0) return hipSuccess;
+    if (!tile_ok(wlen, a.S, NW, a.n_sites, a.ntiles)) return hipErrorInvalidValue;
+    hipError_t e;
+    DPTM_CONV_DISPATCH_BWD(conv_b_bwd_kernel, conv_bwd_lds(NW), conv_bwd_lds(8), kTbMaxParts)
+    if (e != hipSuccess) return e;
+    if ((e = conv_b_bwd_plan(g, plan)) != hipSuccess) return e;
+    PartUnits& ut = plan->units;
+    PartVecs& vt = plan->vecs;
     if (part_sums_deferred(a.ntiles)) return hipSuccess;
     const int grid = (int)(a.ntiles < kTbMaxParts ? a.ntiles : kTbMaxParts);
     e = t_reduce_parts(a.part, grid, ut, vt, st);
@@ -642,22 +703,64 @@ hipError_t t_conv_a_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW,
     DPTM_CONV_DISPATCH_BWD(conv_a_bwd_kernel, conv_bwd_lds(NW), conv_bwd_lds(8), kTbMaxParts)
     if (e != hipSuccess) return e;
     const int grid = (int)(a.ntiles < kTbMaxParts ? a.ntiles : kTbMaxParts);
-    PartUnits& ut = plan->units;
-    PartVecs& vt = plan->vecs;
-    if (ut.n + 5 > kPartMaxUnits || vt.n + 3 > kPartMaxVecs) return hipErrorInvalidValue;
-    float* const unit_dst[5] = {g.c3ak, g.c3ak + 4096, g.c3ak + 2 * 4096, g.sck, g.emb};
-    for (int t = 0; t < 5; ++t) {
-        ut.dst[ut.n] = unit_dst[t];
-        ut.off[ut.n] = kCaBase + t * 4096;
-        ut.ld[ut.n] = 64;
-        ut.rows[ut.n] = t == 4 ? kCodes : 64;       // embedding table [kCodes][64]: only the unit's first kCodes rows exist
-        ++ut.n;
-    }
-    vt.dst[vt.n] = g.c3ab; vt.off[vt.n] = kCaBase + kCaVec; vt.len[vt.n] = 64; ++vt.n;
-    vt.dst[vt.n] = g.scb; vt.off[vt.n] = kCaBase + kCaVec + 64; vt.len[vt.n] = 64; ++vt.n;
-    vt.dst[vt.n] = g.pos; vt.off[vt.n] = kCaBase + kCaPos; vt.len[vt.n] = wlen * 64; ++vt.n;
+    if ((e = conv_a_bwd_plan(g, wlen, plan)) != hipSuccess) return e;
     // every backward launch of the branch has left its partial sums: one launch adds them to the gradients
-    return t_reduce_parts(a.part, grid, ut, vt, st);
+    return t_reduce_parts(a.part, grid, plan->units, plan->vecs, st);
+}
+
+// ---- the three branches in one launch (see conv_a_fwd3_kernel)
+
+static bool branch3_ok(const ConvArgs (&a)[3], int NW) {
+    const int wl[3] = {21, 33, 51};
+    if (NW != 4 && NW != 8) return false;
+    for (int b = 0; b < 3; ++b)
+        if (a[b].n_sites < 1 || a[b].ntiles > kTbMaxParts || !tile_ok(wl[b], a[b].S, NW, a[b].n_sites, a[b].ntiles)) return false;
+    return true;
+}
+
+template <typename K>
+static hipError_t launch_conv3(K kernel, bool (&done)[64], const ConvArgs (&a)[3], int NW, size_t lds, hipStream_t st) {
+    if (!branch3_ok(a, NW)) return hipErrorInvalidValue;
+    hipError_t e = lds_opt_in(kernel, done, lds);
+    if (e != hipSuccess) return e;
+    ConvArgs3 p;
+    int64_t gx = 1;
+    for (int b = 0; b < 3; ++b) {
+        p.a[b] = a[b];
+        gx = a[b].ntiles > gx ? a[b].ntiles : gx;
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)gx, 3), dim3(64 * NW), lds, st, p);
+    return hipGetLastError();
+}
+
+hipError_t t_conv_a_fwd3(const ConvArgs (&a)[3], int NW, hipStream_t st) {
+    static bool d4[64] = {}, d8[64] = {};
+    return NW == 4 ? launch_conv3(&conv_a_fwd3_kernel<256>, d4, a, NW, conv_fwd_lds(4), st)
+                   : launch_conv3(&conv_a_fwd3_kernel<512>, d8, a, NW, conv_fwd_lds(8), st);
+}
+hipError_t t_conv_b_fwd3(const ConvArgs (&a)[3], int NW, hipStream_t st) {
+    static bool d4[64] = {}, d8[64] = {};
+    return NW == 4 ? launch_conv3(&conv_b_fwd3_kernel<256>, d4, a, NW, conv_fwd_lds(4), st)
+                   : launch_conv3(&conv_b_fwd3_kernel<512>, d8, a, NW, conv_fwd_lds(8), st);
+}
+hipError_t t_conv_b_bwd3(const ConvArgs (&a)[3], const ConvGrads (&g)[3], int NW, PartPlan (&plan)[3], hipStream_t st) {
+    static bool d4[64] = {}, d8[64] = {};
+    hipError_t e = NW == 4 ? launch_conv3(&conv_b_bwd3_kernel<256>, d4, a, NW, conv_bwd_lds(4), st)
+                           : launch_conv3(&conv_b_bwd3_kernel<512>, d8, a, NW, conv_bwd_lds(8), st);
+    for (int b = 0; b < 3 && e == hipSuccess; ++b) e = conv_b_bwd_plan(g[b], &plan[b]);
+    return e;
+}
+// ... and, behind the last backward launch, ONE launch that adds the three branches' partial sums to the gradients
+hipError_t t_conv_a_bwd3(const ConvArgs (&a)[3], const ConvGrads (&g)[3], int NW, PartPlan (&plan)[3], hipStream_t st) {
+    static bool d4[64] = {}, d8[64] = {};
+    hipError_t e = NW == 4 ? launch_conv3(&conv_a_bwd3_kernel<256>, d4, a, NW, conv_bwd_lds(4), st)
+                           : launch_conv3(&conv_a_bwd3_kernel<512>, d8, a, NW, conv_bwd_lds(8), st);
+    const int wl[3] = {21, 33, 51};
+    for (int b = 0; b < 3 && e == hipSuccess; ++b) e = conv_a_bwd_plan(g[b], wl[b], &plan[b]);
+    if (e != hipSuccess) return e;
+    const float* parts[3] = {a[0].part, a[1].part, a[2].part};
+    const int nparts[3] = {(int)a[0].ntiles, (int)a[1].ntiles, (int)a[2].ntiles};
+    return t_reduce_parts3(parts, nparts, plan, st);
 }
 
 }  // namespace dptm

@@ -344,6 +344,18 @@ hipError_t t_conv_b_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW,
 hipError_t t_conv_a_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW, PartPlan* plan, hipStream_t st);   // dz1, dx1 -> conv3a / shortcut / BN1 / embedding gradients
 
 
+// ---- the same launch of the three sequence branches (windows 21 | 33 | 51, in that order) as ONE launch, for batches
+// with a tile per workgroup in every branch (tiles of NW = 4 or 8 wavefronts): such a batch's step is then a chain of
+// launches on ONE stream, with no hand-over between streams on its critical path.  t_conv_a_bwd3 ends with the one
+// launch that adds the three branches' partial sums to the gradients.
+hipError_t t_conv_a_fwd3(const ConvArgs (&a)[3], int NW, hipStream_t st);
+hipError_t t_conv_b_fwd3(const ConvArgs (&a)[3], int NW, hipStream_t st);
+hipError_t t_tb_fwd3(const TbFwdArgs (&a)[3], int NW, hipStream_t st);
+hipError_t t_tb_bwd3(const TbBwdArgs (&a)[3], const TbGrads (&g)[3], int NW, PartPlan (&plan)[3], hipStream_t st);
+hipError_t t_conv_b_bwd3(const ConvArgs (&a)[3], const ConvGrads (&g)[3], int NW, PartPlan (&plan)[3], hipStream_t st);
+hipError_t t_conv_a_bwd3(const ConvArgs (&a)[3], const ConvGrads (&g)[3], int NW, PartPlan (&plan)[3], hipStream_t st);
+hipError_t t_reduce_parts3(const float* const (&part)[3], const int (&nparts)[3], const PartPlan (&plan)[3], hipStream_t st);
+
 // ---- per-site dense layers for small batches (dptm_train_site.hip)
 constexpr int kSiteMaxRows = 128;
 // inverted dropout on the stateless hash: element (row r, column c) has index r*cols + col0 + c; thr 0: none
