@@ -194,8 +194,6 @@ float* g_scratch_ptr[kMaxDevices] = {};
 struct dptm_handle {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t aux[3] = {nullptr, nullptr, nullptr};     // side streams of the small-call path
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     float* d_branch[3] = {nullptr, nullptr, nullptr};
     uint16_t* d_branch_half[3][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};  // [branch][bf16 | f16 hi | f16 lo]
     int precision = kModeF32;
@@ -205,6 +203,9 @@ struct dptm_handle {
     Workspace ws;                         // per-pass workspace (ws_cap rows: kChunkSites, or kPassSites once a call needed more)
     int64_t ws_cap = 0;
     bool plain = false;                   // set for the duration of a call that may create no stream or event
+    // small host-array calls (at most kDenseSmallRows sites): ONE pinned block and its device twin, so that the five
+    // input arrays cross PCIe as one copy from pinned memory instead of five from pageable memory
+    uint8_t *small_pin = nullptr, *small_dev = nullptr;
     float* d_zero_row = nullptr;
     // per-chunk staging for assembled windows
     uint8_t* d_tok[3] = {nullptr, nullptr, nullptr};
@@ -441,32 +442,32 @@ int run_dense(dptm_handle* h, const DenseLayer& L, int epi, const float* x, int6
 // esm_half: the ESM rows hold the mode's bfloat16 / float16 values (what the host pipelines send in those modes)
 int score_chunk(dptm_handle* h, const Workspace& ws, const uint8_t* const tok[3], const float* strct, const float* esm,
                 int64_t esm_ld, const int32_t* esm_row, int64_t m, float* out, hipStream_t st, bool esm_half = false) {
-    // A small call cannot fill the chip with any one kernel, so its three sequence branches run on side
-    // streams next to the structure / ESM layers; a large call keeps everything on one stream.
-    const bool fan_out = m <= kDenseSmallRows && !h->prof_armed && !h->plain;
-    if (fan_out && !h->ev_fork) {
-        for (int b = 0; b < 3; ++b) {
-            HIP_TRY(hipStreamCreateWithFlags(&h->aux[b], hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&h->ev_join[b], hipEventDisableTiming));
-        }
-        HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-    }
-    if (fan_out) HIP_TRY(hipEventRecord(h->ev_fork, st));
-    for (int b = 0; b < 3; ++b) {
-        hipStream_t bs = st;
-        if (fan_out) {
-            bs = h->aux[b];
-            HIP_TRY(hipStreamWaitEvent(bs, h->ev_fork, 0));
-        }
-        Prof p(h, bs, DPTM_PROF_BRANCH21 + b);
+    // A small call cannot fill the chip with any one kernel, and its duration is one wavefront chain per branch: its
+    // three sequence branches are ONE launch (grid.y = branch).  (As three launches on three side streams the call
+    // paid two hand-overs between streams, and the chain twice over whenever two of those streams landed on one hardware
+    // queue: 362 us for 53 sites against 202 us now.)  A large call starts a launch per branch, on one stream.
+    const bool merged = m <= kDenseSmallRows && !h->prof_armed;
+    if (merged) {
+        const float* const params[3] = {h->d_branch[0], h->d_branch[1], h->d_branch[2]};
+        const uint8_t* const toks[3] = {tok[0], tok[1], tok[2]};
         if (h->precision == kModeF32) {
-            HIP_TRY(launch_branch(kWin[b], h->d_branch[b], tok[b], m, ws.concat, kConcat, b * kD, bs));
+            HIP_TRY(launch_branch3(params, toks, m, ws.concat, kConcat, st));
+        } else {
+            const int hi = h->precision == kModeBF16 ? 0 : 1;
+            const void* const whi[3] = {h->d_branch_half[0][hi], h->d_branch_half[1][hi], h->d_branch_half[2][hi]};
+            const void* const wlo[3] = {h->d_branch_half[0][2], h->d_branch_half[1][2], h->d_branch_half[2][2]};
+            HIP_TRY(launch_branch3_h(h->precision, params, whi, wlo, toks, m, ws.concat, kConcat, st));
+        }
+    }
+    for (int b = 0; b < 3 && !merged; ++b) {
+        Prof p(h, st, DPTM_PROF_BRANCH21 + b);
+        if (h->precision == kModeF32) {
+            HIP_TRY(launch_branch(kWin[b], h->d_branch[b], tok[b], m, ws.concat, kConcat, b * kD, st));
         } else {
             const uint16_t* hi = h->d_branch_half[b][h->precision == kModeBF16 ? 0 : 1];
             HIP_TRY(launch_branch_h(h->precision, kWin[b], h->d_branch[b], hi, h->d_branch_half[b][2], tok[b], m,
-                                    ws.concat, kConcat, b * kD, bs));
+                                    ws.concat, kConcat, b * kD, st));
         }
-        if (fan_out) HIP_TRY(hipEventRecord(h->ev_join[b], bs));
     }
     int rc;
     if ((rc = run_dense(h, h->strct, kEpiSwishAffine, strct, kStruct, nullptr, m, ws.concat, kConcat,
@@ -478,8 +479,6 @@ int score_chunk(dptm_handle* h, const Workspace& ws, const uint8_t* const tok[3]
     if ((rc = run_dense(h, h->esm2, kEpiSwish, ws.h1, kEsm1, nullptr, m, ws.concat, kConcat,
                         3 * kD + kStructUnits, st, DPTM_PROF_ESM2)))
         return rc;
-    if (fan_out)
-        for (int b = 0; b < 3; ++b) HIP_TRY(hipStreamWaitEvent(st, h->ev_join[b], 0));
     if ((rc = run_dense(h, h->t1, kEpiSwishAffine, ws.concat, kConcat, nullptr, m, ws.t1, kT1, 0, st,
                         DPTM_PROF_TRUNK1)))
         return rc;
@@ -809,14 +808,8 @@ void dptm_destroy(dptm_handle* h) {
         if (h->s_tok[b]) (void)hipFree(h->s_tok[b]);
         if (h->s2_tok[b]) (void)hipFree(h->s2_tok[b]);
     }
-    for (int b = 0; b < 3; ++b) {
-        if (h->aux[b]) {
-            (void)hipStreamSynchronize(h->aux[b]);
-            (void)hipStreamDestroy(h->aux[b]);
-        }
-        if (h->ev_join[b]) (void)hipEventDestroy(h->ev_join[b]);
-    }
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->small_pin) (void)hipHostFree(h->small_pin);
+    if (h->small_dev) (void)hipFree(h->small_dev);
     if (h->copy_stream) {
         (void)hipStreamSynchronize(h->copy_stream);
         (void)hipStreamDestroy(h->copy_stream);
@@ -1090,6 +1083,36 @@ static int score_host_rows(dptm_handle* h, const uint8_t* tok21, const uint8_t* 
     int rc = ensure_host_staging(h);
     if (rc) return rc;
     DrainOnError drain{h};
+    if (n <= kDenseSmallRows && !rows16) {
+        // a protein's worth of sites: the call is latency -- the inputs are packed into one pinned block and cross
+        // PCIe as ONE copy (five copies from pageable memory cost ~60 us more), the probabilities come back through it
+        const size_t o_struct = (size_t)n * kEsm * sizeof(float), o_tok0 = o_struct + (size_t)n * kStruct * sizeof(float);
+        const size_t o_tok1 = (o_tok0 + (size_t)n * kWin[0] + 15) & ~(size_t)15, o_tok2 = (o_tok1 + (size_t)n * kWin[1] + 15) & ~(size_t)15;
+        const size_t o_out = (o_tok2 + (size_t)n * kWin[2] + 15) & ~(size_t)15, total = o_out + (size_t)n * 2 * sizeof(float);
+        constexpr size_t kSmallBytes = (size_t)kDenseSmallRows * (kEsm * 4 + kStruct * 4 + 21 + 33 + 51 + 8) + 64;
+        if (!h->small_pin) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h->small_pin), kSmallBytes, hipHostMallocDefault));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->small_dev), kSmallBytes));
+        }
+        if (total > kSmallBytes) return fail(DPTM_EINVAL, "dptm_score: small-call staging");
+        uint8_t *pin = h->small_pin, *dev = h->small_dev;
+        std::memcpy(pin, esm, o_struct);
+        std::memcpy(pin + o_struct, strct, (size_t)n * kStruct * sizeof(float));
+        std::memcpy(pin + o_tok0, tok21, (size_t)n * kWin[0]);
+        std::memcpy(pin + o_tok1, tok33, (size_t)n * kWin[1]);
+        std::memcpy(pin + o_tok2, tok51, (size_t)n * kWin[2]);
+        HIP_TRY(hipMemcpyAsync(dev, pin, o_out, hipMemcpyHostToDevice, h->stream));
+        const uint8_t* tok[3] = {dev + o_tok0, dev + o_tok1, dev + o_tok2};
+        float* d_out = reinterpret_cast<float*>(dev + o_out);
+        if ((rc = score_chunk(h, h->ws, tok, reinterpret_cast<const float*>(dev + o_struct), reinterpret_cast<const float*>(dev), kEsm,
+                              nullptr, n, d_out, h->stream)))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(pin + o_out, d_out, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        std::memcpy(out, pin + o_out, (size_t)n * 2 * sizeof(float));
+        drain.armed = false;
+        return DPTM_OK;
+    }
     if (n <= kChunkSites) {
         // one pass: nothing to overlap, and the pinned staging blocks of the pipeline (2 x 172 MB) are not
         // worth allocating for a protein's worth of sites

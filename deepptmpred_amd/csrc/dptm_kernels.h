@@ -33,9 +33,14 @@ struct DenseArgs {
     int col_off;
 };
 
+// the three sequence branches of a small call in one launch: columns 0 | 64 | 128 of out (windows 21 | 33 | 51)
+hipError_t launch_branch3(const float* const (&params)[3], const uint8_t* const (&tok)[3], int64_t n, float* out, int ldo,
+                          hipStream_t st);
 hipError_t launch_branch(int w, const float* params, const uint8_t* tok, int64_t n, float* out,
                          int ldo, int col_off, hipStream_t st);
 // half-precision-MFMA branch (dptm_kernels_h.hip): whi/wlo = packed half weight images of the branch
+hipError_t launch_branch3_h(int mode, const float* const (&params)[3], const void* const (&whi)[3], const void* const (&wlo)[3],
+                            const uint8_t* const (&tok)[3], int64_t n, float* out, int ldo, hipStream_t st);
 hipError_t launch_branch_h(int mode, int w, const float* params, const void* whi, const void* wlo, const uint8_t* tok,
                            int64_t n, float* out, int ldo, int col_off, hipStream_t st);
 hipError_t launch_dense(const DenseArgs& a, int epi, hipStream_t st);

@@ -38,10 +38,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 //   pooling:     bufA = final activations, plus one score per row.
 // ------------------------------------------------------------------------------------
 template <int W>
-__global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P,
-                                                     const uint8_t* __restrict__ tok,
-                                                     int64_t n_sites, float* __restrict__ out,
-                                                     int ldo, int col_off) {
+__device__ __forceinline__ void branch_body(const f32x4* __restrict__ P, const uint8_t* __restrict__ tok,
+                                            int64_t n_sites, float* __restrict__ out, int ldo, int col_off) {
     constexpr int S = kTileRows / W;  // sites per tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* bufA = lds;
@@ -722,6 +720,35 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
     }
 }
 
+template <int W>
+__global__ __launch_bounds__(512) void branch_kernel(const f32x4* __restrict__ P,
+                                                     const uint8_t* __restrict__ tok,
+                                                     int64_t n_sites, float* __restrict__ out,
+                                                     int ldo, int col_off) {
+    branch_body<W>(P, tok, n_sites, out, ldo, col_off);
+}
+
+// The three window sizes of a SMALL call in one launch (grid.y = 0: W = 51, whose workgroups are handed out first;
+// grid.x = the most tiles a branch has, a workgroup beyond its branch's tiles leaves at once): a call of a protein's
+// worth of sites is one wavefront chain per branch, and as three launches on three streams it paid two hand-overs
+// between streams -- and twice the chain whenever two of those streams shared a hardware queue.
+struct Branch3Args {
+    const f32x4* P[3];          // windows 21 | 33 | 51
+    const uint8_t* tok[3];
+    int64_t n_sites;
+    float* out;
+    int ldo;
+};
+__global__ __launch_bounds__(512) void branch3_kernel(Branch3Args p) {
+    if (blockIdx.y == 2) {
+        if ((int64_t)blockIdx.x * (kTileRows / 21) < p.n_sites) branch_body<21>(p.P[0], p.tok[0], p.n_sites, p.out, p.ldo, 0);
+    } else if (blockIdx.y == 1) {
+        if ((int64_t)blockIdx.x * (kTileRows / 33) < p.n_sites) branch_body<33>(p.P[1], p.tok[1], p.n_sites, p.out, p.ldo, kD);
+    } else {
+        if ((int64_t)blockIdx.x * (kTileRows / 51) < p.n_sites) branch_body<51>(p.P[2], p.tok[2], p.n_sites, p.out, p.ldo, 2 * kD);
+    }
+}
+
 // ------------------------------------------------------------------------------------ launchers
 
 static constexpr size_t kBranchLds = (2 * kTileRows * kLdsStride + kTileRows) * sizeof(float) + kVecsF4 * 16;
@@ -750,6 +777,37 @@ static hipError_t launch_branch_t(const float* params, const uint8_t* tok, int64
     if (blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(branch_kernel<W>, dim3((unsigned)blocks), dim3(512), kBranchLds, st,
                        reinterpret_cast<const f32x4*>(params), tok, n, out, ldo, col_off);
+    return hipGetLastError();
+}
+
+static hipError_t branch3_attr(int dev) {
+    static bool attr_done_dev[64] = {};
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (attr_done_dev[dev]) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&branch3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)kBranchLds);
+    if (e == hipSuccess) attr_done_dev[dev] = true;
+    return e;
+}
+
+hipError_t launch_branch3(const float* const (&params)[3], const uint8_t* const (&tok)[3], int64_t n, float* out, int ldo,
+                          hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if ((e = branch3_attr(dev)) != hipSuccess) return e;
+    Branch3Args p;
+    for (int b = 0; b < 3; ++b) {
+        p.P[b] = reinterpret_cast<const f32x4*>(params[b]);
+        p.tok[b] = tok[b];
+    }
+    p.n_sites = n;
+    p.out = out;
+    p.ldo = ldo;
+    constexpr int S51 = kTileRows / 51;
+    const int64_t blocks = (n + S51 - 1) / S51;      // W = 51 has the fewest sites per tile, hence the most tiles
+    hipLaunchKernelGGL(branch3_kernel, dim3((unsigned)blocks, 3), dim3(512), kBranchLds, st, p);
     return hipGetLastError();
 }
 
@@ -815,7 +873,8 @@ hipError_t prepare_kernels() {
     if (e != hipSuccess) return e;
     if ((e = branch_attr<21>(dev)) != hipSuccess) return e;
     if ((e = branch_attr<33>(dev)) != hipSuccess) return e;
-    return branch_attr<51>(dev);
+    if ((e = branch_attr<51>(dev)) != hipSuccess) return e;
+    return branch3_attr(dev);
 }
 
 }  // namespace dptm

@@ -224,9 +224,9 @@ struct WBuf {
 };
 
 template <int W, int MODE>
-__global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__ P, const uint4* __restrict__ Whi,
-                                                       const uint4* __restrict__ Wlo, const uint8_t* __restrict__ tok,
-                                                       int64_t n_sites, float* __restrict__ out, int ldo, int col_off) {
+__device__ __forceinline__ void branch_h_body(const f32x4* __restrict__ P, const uint4* __restrict__ Whi,
+                                              const uint4* __restrict__ Wlo, const uint8_t* __restrict__ tok,
+                                              int64_t n_sites, float* __restrict__ out, int ldo, int col_off) {
     typedef typename HP<MODE>::elem E;
     constexpr int S = kTileRows / W;
     constexpr int MAXNB = (W == 51) ? 5 : 4;
@@ -1011,6 +1011,37 @@ hipError_t launch_dense_h(int mode, const DenseArgs& a, int epi, const void* whi
     }
 }
 
+template <int W, int MODE>
+__global__ __launch_bounds__(512) void branch_kernel_h(const f32x4* __restrict__ P, const uint4* __restrict__ Whi,
+                                                       const uint4* __restrict__ Wlo, const uint8_t* __restrict__ tok,
+                                                       int64_t n_sites, float* __restrict__ out, int ldo, int col_off) {
+    branch_h_body<W, MODE>(P, Whi, Wlo, tok, n_sites, out, ldo, col_off);
+}
+
+// the three window sizes of a small call in one launch (grid.y = 0: W = 51), as branch3_kernel does in fp32
+struct Branch3ArgsH {
+    const f32x4* P[3];          // windows 21 | 33 | 51
+    const uint4* Whi[3];
+    const uint4* Wlo[3];
+    const uint8_t* tok[3];
+    int64_t n_sites;
+    float* out;
+    int ldo;
+};
+template <int MODE>
+__global__ __launch_bounds__(512) void branch3_kernel_h(Branch3ArgsH p) {
+    if (blockIdx.y == 2) {
+        if ((int64_t)blockIdx.x * (kTileRows / 21) < p.n_sites)
+            branch_h_body<21, MODE>(p.P[0], p.Whi[0], p.Wlo[0], p.tok[0], p.n_sites, p.out, p.ldo, 0);
+    } else if (blockIdx.y == 1) {
+        if ((int64_t)blockIdx.x * (kTileRows / 33) < p.n_sites)
+            branch_h_body<33, MODE>(p.P[1], p.Whi[1], p.Wlo[1], p.tok[1], p.n_sites, p.out, p.ldo, kD);
+    } else {
+        if ((int64_t)blockIdx.x * (kTileRows / 51) < p.n_sites)
+            branch_h_body<51, MODE>(p.P[2], p.Whi[2], p.Wlo[2], p.tok[2], p.n_sites, p.out, p.ldo, 2 * kD);
+    }
+}
+
 static constexpr size_t kBranchLdsH = 2 * (size_t)kRegionB + kTileRows * sizeof(float) + kVecsF4 * 16 + 13 * 2 * 16;
 
 // the LDS opt-in of one instance on the current device (per device: remembered for every device of this process)
@@ -1030,10 +1061,23 @@ static hipError_t branch_h_opt_in() {
 }
 
 template <int MODE>
+static hipError_t branch3_h_opt_in() {
+    static bool attr_done_dev[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (attr_done_dev[dev]) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&branch3_kernel_h<MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBranchLdsH);
+    if (e == hipSuccess) attr_done_dev[dev] = true;
+    return e;
+}
+
+template <int MODE>
 static hipError_t branch_h_opt_in_mode() {
     hipError_t e = branch_h_opt_in<21, MODE>();
     if (e == hipSuccess) e = branch_h_opt_in<33, MODE>();
     if (e == hipSuccess) e = branch_h_opt_in<51, MODE>();
+    if (e == hipSuccess) e = branch3_h_opt_in<MODE>();
     return e;
 }
 
@@ -1068,6 +1112,37 @@ static hipError_t launch_branch_h_m(int w, const float* params, const void* whi,
         case 21: return launch_branch_h_t<21, MODE>(params, whi, wlo, tok, n, out, ldo, col_off, st);
         case 33: return launch_branch_h_t<33, MODE>(params, whi, wlo, tok, n, out, ldo, col_off, st);
         case 51: return launch_branch_h_t<51, MODE>(params, whi, wlo, tok, n, out, ldo, col_off, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int MODE>
+static hipError_t launch_branch3_h_m(const float* const (&params)[3], const void* const (&whi)[3], const void* const (&wlo)[3],
+                                     const uint8_t* const (&tok)[3], int64_t n, float* out, int ldo, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (hipError_t e = branch3_h_opt_in<MODE>(); e != hipSuccess) return e;
+    Branch3ArgsH p;
+    for (int b = 0; b < 3; ++b) {
+        p.P[b] = reinterpret_cast<const f32x4*>(params[b]);
+        p.Whi[b] = reinterpret_cast<const uint4*>(whi[b]);
+        p.Wlo[b] = reinterpret_cast<const uint4*>(wlo[b]);
+        p.tok[b] = tok[b];
+    }
+    p.n_sites = n;
+    p.out = out;
+    p.ldo = ldo;
+    constexpr int S51 = kTileRows / 51;
+    const int64_t blocks = (n + S51 - 1) / S51;      // W = 51 has the most tiles
+    hipLaunchKernelGGL(branch3_kernel_h<MODE>, dim3((unsigned)blocks, 3), dim3(512), kBranchLdsH, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_branch3_h(int mode, const float* const (&params)[3], const void* const (&whi)[3], const void* const (&wlo)[3],
+                            const uint8_t* const (&tok)[3], int64_t n, float* out, int ldo, hipStream_t st) {
+    switch (mode) {
+        case kModeBF16: return launch_branch3_h_m<kModeBF16>(params, whi, wlo, tok, n, out, ldo, st);
+        case kModeF16: return launch_branch3_h_m<kModeF16>(params, whi, wlo, tok, n, out, ldo, st);
+        case kModeF16X3: return launch_branch3_h_m<kModeF16X3>(params, whi, wlo, tok, n, out, ldo, st);
         default: return hipErrorInvalidValue;
     }
 }
