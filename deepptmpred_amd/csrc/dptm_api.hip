@@ -409,9 +409,8 @@ struct Prof {
     }
 };
 
-int run_dense(dptm_handle* h, const DenseLayer& L, int epi, const float* x, int64_t ldx,
-              const int32_t* row_index, int64_t m, float* out, int64_t ldo, int col_off,
-              hipStream_t st, int cls, bool x_half = false) {
+DenseArgs dense_args(const DenseLayer& L, const float* x, int64_t ldx, const int32_t* row_index, int64_t m, float* out,
+                     int64_t ldo, int col_off, bool x_half = false) {
     DenseArgs a;
     a.x = x;
     a.ldx = ldx;
@@ -427,6 +426,13 @@ int run_dense(dptm_handle* h, const DenseLayer& L, int epi, const float* x, int6
     a.out = out;
     a.ldo = ldo;
     a.col_off = col_off;
+    return a;
+}
+
+int run_dense(dptm_handle* h, const DenseLayer& L, int epi, const float* x, int64_t ldx,
+              const int32_t* row_index, int64_t m, float* out, int64_t ldo, int col_off,
+              hipStream_t st, int cls, bool x_half = false) {
+    const DenseArgs a = dense_args(L, x, ldx, row_index, m, out, ldo, col_off, x_half);
     Prof p(h, st, cls);
     if (x_half && (h->precision == kModeF32 || h->precision == kModeF16X3 || !L.d_w_half[0]))
         return fail(DPTM_EINVAL, "16-bit input rows need the bf16 or f16 mode");
@@ -447,10 +453,17 @@ int score_chunk(dptm_handle* h, const Workspace& ws, const uint8_t* const tok[3]
     // paid two hand-overs between streams, and the chain twice over whenever two of those streams landed on one hardware
     // queue: 362 us for 53 sites against 202 us now.)  A large call starts a launch per branch, on one stream.
     const bool merged = m <= kDenseSmallRows && !h->prof_armed;
+    bool front = false;      // the structure and first ESM layer went out with the branches
     if (merged) {
         const float* const params[3] = {h->d_branch[0], h->d_branch[1], h->d_branch[2]};
         const uint8_t* const toks[3] = {tok[0], tok[1], tok[2]};
-        if (h->precision == kModeF32) {
+        if (h->precision == kModeF32 && !esm_half) {
+            // ... together with the two layers that depend on the inputs only (structure, first ESM layer)
+            front = true;
+            HIP_TRY(launch_front5(params, toks, m, ws.concat, kConcat,
+                                  dense_args(h->strct, strct, kStruct, nullptr, m, ws.concat, kConcat, 3 * kD),
+                                  dense_args(h->esm1, esm, esm_ld, esm_row, m, ws.h1, kEsm1, 0), st));
+        } else if (h->precision == kModeF32) {
             HIP_TRY(launch_branch3(params, toks, m, ws.concat, kConcat, st));
         } else {
             const int hi = h->precision == kModeBF16 ? 0 : 1;
@@ -470,11 +483,11 @@ int score_chunk(dptm_handle* h, const Workspace& ws, const uint8_t* const tok[3]
         }
     }
     int rc;
-    if ((rc = run_dense(h, h->strct, kEpiSwishAffine, strct, kStruct, nullptr, m, ws.concat, kConcat,
-                        3 * kD, st, DPTM_PROF_STRUCT)))
+    if (!front && (rc = run_dense(h, h->strct, kEpiSwishAffine, strct, kStruct, nullptr, m, ws.concat, kConcat,
+                                  3 * kD, st, DPTM_PROF_STRUCT)))
         return rc;
-    if ((rc = run_dense(h, h->esm1, kEpiSwishAffine, esm, esm_ld, esm_row, m, ws.h1, kEsm1, 0, st,
-                        DPTM_PROF_ESM1, esm_half)))
+    if (!front && (rc = run_dense(h, h->esm1, kEpiSwishAffine, esm, esm_ld, esm_row, m, ws.h1, kEsm1, 0, st,
+                                  DPTM_PROF_ESM1, esm_half)))
         return rc;
     if ((rc = run_dense(h, h->esm2, kEpiSwish, ws.h1, kEsm1, nullptr, m, ws.concat, kConcat,
                         3 * kD + kStructUnits, st, DPTM_PROF_ESM2)))

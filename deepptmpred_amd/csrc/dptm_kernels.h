@@ -36,6 +36,9 @@ struct DenseArgs {
 // the three sequence branches of a small call in one launch: columns 0 | 64 | 128 of out (windows 21 | 33 | 51)
 hipError_t launch_branch3(const float* const (&params)[3], const uint8_t* const (&tok)[3], int64_t n, float* out, int ldo,
                           hipStream_t st);
+// ... together with the structure layer and the first ESM layer (DenseArgs of m = n rows, swish + affine epilogue)
+hipError_t launch_front5(const float* const (&params)[3], const uint8_t* const (&tok)[3], int64_t n, float* out, int ldo,
+                         const DenseArgs& strct, const DenseArgs& esm1, hipStream_t st);
 hipError_t launch_branch(int w, const float* params, const uint8_t* tok, int64_t n, float* out,
                          int ldo, int col_off, hipStream_t st);
 // half-precision-MFMA branch (dptm_kernels_h.hip): whi/wlo = packed half weight images of the branch

@@ -12,6 +12,8 @@
 // (register, half-wave); see dptm_layout.h for the register map ("chain layout").
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "dptm_layout.h"
 #include "dptm_attend.h"
 #include "dptm_mfma.h"
@@ -499,13 +501,13 @@ __global__ __launch_bounds__(256, 2) void dense_kernel(DenseArgs p) {
 // 32 columns and its 8 wavefronts split the contraction; partial tiles meet in LDS, where the bias and
 // the epilogue are applied.  grid = (ceil(m/32), n_pad/32), block 512.
 // ------------------------------------------------------------------------------------
+// part: 32 KB of LDS, [8 wavefronts][16 registers][64 lanes]; (bx, by): row tile and column tile of this workgroup
 template <int EPI>
-__global__ __launch_bounds__(512) void dense_small_kernel(DenseArgs p) {
-    __shared__ float part[8][16][64];
+__device__ __forceinline__ void dense_small_body(const DenseArgs& p, float (*part)[16][64], int bx, int by) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, j = lane & 31;
-    const int64_t r0 = (int64_t)blockIdx.x * 32;
-    const int tile = blockIdx.y;
+    const int64_t r0 = (int64_t)bx * 32;
+    const int tile = by;
     const int k8 = p.k >> 3;
     const int per = (k8 + 7) / 8;
     const int u0 = wave * per, u1 = min(k8, u0 + per);
@@ -557,6 +559,47 @@ __global__ __launch_bounds__(512) void dense_small_kernel(DenseArgs p) {
             v = fmaf(v, reinterpret_cast<const float*>(p.scale + vi)[e], reinterpret_cast<const float*>(p.shift + vi)[e]);
         p.out[row * p.ldo + p.col_off + tile * 32 + 8 * g + 4 * hh + e] = v;
     }
+}
+
+// The 2-class head of a small call: softmax(x W + b) for 32 rows per workgroup, eight threads per row over the
+// contraction (the throughput tiling walks it in one wavefront: 14 us for 53 rows against 4).  Reads the packed weight
+// image: W[k][n] sits in element k & 3 of fragment (k >> 3) * 64 + n + 32 * ((k >> 2) & 1).
+__global__ __launch_bounds__(256) void head_small_kernel(DenseArgs p) {
+    const int r = blockIdx.x * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+    const int64_t row = r < p.m ? r : p.m - 1;
+    const float* x = p.x + row * p.ldx;
+    float l0 = 0.f, l1 = 0.f;
+    for (int k4 = part; k4 < (p.k >> 2); k4 += 8) {          // four consecutive inputs per step
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + 4 * k4);
+        const int frag = (k4 >> 1) * 64 + 32 * (k4 & 1);
+        const f32x4 w0 = p.w[frag], w1 = p.w[frag + 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            l0 = fmaf(xv[e], w0[e], l0);
+            l1 = fmaf(xv[e], w1[e], l1);
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        l0 += __shfl_xor(l0, o);
+        l1 += __shfl_xor(l1, o);
+    }
+    if (part == 0 && r < p.m) {
+        const float* b = reinterpret_cast<const float*>(p.bias);
+        l0 += b[0];
+        l1 += b[1];
+        const float m = fmaxf(l0, l1);
+        const float e0 = __expf(l0 - m), e1 = __expf(l1 - m);
+        const float rs = 1.0f / (e0 + e1);
+        float2 o = {e0 * rs, e1 * rs};
+        *reinterpret_cast<float2*>(p.out + (int64_t)r * p.ldo) = o;
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void dense_small_kernel(DenseArgs p) {
+    __shared__ float part[8][16][64];
+    dense_small_body<EPI>(p, part, blockIdx.x, blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------
@@ -749,6 +792,29 @@ __global__ __launch_bounds__(512) void branch3_kernel(Branch3Args p) {
     }
 }
 
+// ... and with the two layers that depend on the call's inputs only -- the structure layer and the first ESM layer
+// (both swish + folded BatchNorm, small-call tiling) -- as grid.y = 3 and 4 of the same launch: everything of a small
+// call that can start at once starts at once.
+struct Front5Args {
+    Branch3Args br;
+    DenseArgs strct, esm1;
+};
+__global__ __launch_bounds__(512) void front5_kernel(Front5Args p) {
+    extern __shared__ __attribute__((aligned(16))) float lds_front[];
+    if (blockIdx.y == 0) {
+        if ((int64_t)blockIdx.x * (kTileRows / 51) < p.br.n_sites) branch_body<51>(p.br.P[2], p.br.tok[2], p.br.n_sites, p.br.out, p.br.ldo, 2 * kD);
+    } else if (blockIdx.y == 1) {
+        if ((int64_t)blockIdx.x * (kTileRows / 33) < p.br.n_sites) branch_body<33>(p.br.P[1], p.br.tok[1], p.br.n_sites, p.br.out, p.br.ldo, kD);
+    } else if (blockIdx.y == 2) {
+        if ((int64_t)blockIdx.x * (kTileRows / 21) < p.br.n_sites) branch_body<21>(p.br.P[0], p.br.tok[0], p.br.n_sites, p.br.out, p.br.ldo, 0);
+    } else {
+        const DenseArgs& d = blockIdx.y == 3 ? p.strct : p.esm1;
+        const int ctiles = d.n_pad >> 5, rtiles = (int)((d.m + 31) >> 5);
+        if ((int)blockIdx.x < ctiles * rtiles)
+            dense_small_body<kEpiSwishAffine>(d, reinterpret_cast<float (*)[16][64]>(lds_front), (int)blockIdx.x / ctiles, (int)blockIdx.x % ctiles);
+    }
+}
+
 // ------------------------------------------------------------------------------------ launchers
 
 static constexpr size_t kBranchLds = (2 * kTileRows * kLdsStride + kTileRows) * sizeof(float) + kVecsF4 * 16;
@@ -811,6 +877,43 @@ hipError_t launch_branch3(const float* const (&params)[3], const uint8_t* const 
     return hipGetLastError();
 }
 
+static hipError_t front5_attr(int dev) {
+    static bool attr_done_dev[64] = {};
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (attr_done_dev[dev]) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&front5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)kBranchLds);
+    if (e == hipSuccess) attr_done_dev[dev] = true;
+    return e;
+}
+
+hipError_t launch_front5(const float* const (&params)[3], const uint8_t* const (&tok)[3], int64_t n, float* out, int ldo,
+                         const DenseArgs& strct, const DenseArgs& esm1, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    if (strct.m != n || esm1.m != n || n > kDenseSmallRows || strct.n_pad % 32 != 0 || esm1.n_pad % 32 != 0) return hipErrorInvalidValue;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if ((e = front5_attr(dev)) != hipSuccess) return e;
+    Front5Args p;
+    for (int b = 0; b < 3; ++b) {
+        p.br.P[b] = reinterpret_cast<const f32x4*>(params[b]);
+        p.br.tok[b] = tok[b];
+    }
+    p.br.n_sites = n;
+    p.br.out = out;
+    p.br.ldo = ldo;
+    p.strct = strct;
+    p.esm1 = esm1;
+    constexpr int S51 = kTileRows / 51;
+    const int64_t rtiles = (n + 31) / 32;
+    int64_t gx = (n + S51 - 1) / S51;
+    gx = std::max<int64_t>(gx, rtiles * (strct.n_pad / 32));
+    gx = std::max<int64_t>(gx, rtiles * (esm1.n_pad / 32));
+    hipLaunchKernelGGL(front5_kernel, dim3((unsigned)gx, 5), dim3(512), kBranchLds, st, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_branch(int w, const float* params, const uint8_t* tok, int64_t n, float* out,
                          int ldo, int col_off, hipStream_t st) {
     switch (w) {
@@ -832,6 +935,10 @@ hipError_t launch_dense(const DenseArgs& a, int epi, hipStream_t st) {
             hipLaunchKernelGGL((dense_small_kernel<kEpiSwishAffine>), grid, dim3(512), 0, st, a);
         else
             return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
+    if (epi == kEpiHead && a.m <= kDenseSmallRows && a.k % 4 == 0 && !a.row_index) {
+        hipLaunchKernelGGL(head_small_kernel, dim3((unsigned)((a.m + 31) / 32)), dim3(256), 0, st, a);
         return hipGetLastError();
     }
     const unsigned gx = (unsigned)((a.m + 255) / 256);
@@ -874,6 +981,7 @@ hipError_t prepare_kernels() {
     if ((e = branch_attr<21>(dev)) != hipSuccess) return e;
     if ((e = branch_attr<33>(dev)) != hipSuccess) return e;
     if ((e = branch_attr<51>(dev)) != hipSuccess) return e;
+    if ((e = front5_attr(dev)) != hipSuccess) return e;
     return branch3_attr(dev);
 }
 
