@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "dptm_layout.h"
 #include "dptm_attend.h"
@@ -39,17 +40,21 @@ __device__ __forceinline__ void wave_lds_fence() {
 //                in registers;
 //   pooling:     bufA = final activations, plus one score per row.
 // ------------------------------------------------------------------------------------
-template <int W>
+// TR: rows of the tile (256: eight wavefronts, the throughput form; 64: two wavefronts, one per SIMD, for small calls,
+// whose duration is one wavefront's chain -- which is shorter when the wavefront has its SIMD to itself)
+template <int W, int TR = kTileRows>
 __device__ __forceinline__ void branch_body(const f32x4* __restrict__ P, const uint8_t* __restrict__ tok,
                                             int64_t n_sites, float* __restrict__ out, int ldo, int col_off) {
-    constexpr int S = kTileRows / W;  // sites per tile
+    constexpr int S = TR / W;  // sites per tile
+    constexpr int NT = 2 * TR;  // threads of the workgroup
+    static_assert(S >= 1, "a tile holds whole sites");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* bufA = lds;
-    float* bufB = lds + kTileRows * kLdsStride;
-    float* score = bufB + kTileRows * kLdsStride;  // [256]
+    float* bufB = lds + TR * kLdsStride;
+    float* score = bufB + TR * kLdsStride;  // [TR]
     // bias / scale / LayerNorm vectors of the whole branch, copied once per workgroup: read from
     // memory they cost the texture path as many instructions as the weight fragments do
-    f32x4* vecs = reinterpret_cast<f32x4*>(score + kTileRows);
+    f32x4* vecs = reinterpret_cast<f32x4*>(score + TR);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -61,9 +66,9 @@ __device__ __forceinline__ void branch_body(const f32x4* __restrict__ P, const u
     const int rows_valid = sites_here * W;
 
     PH_DECL
-    for (int i = tid; i < kVecsF4; i += 512) vecs[i] = P[vecs_source(i)];
+    for (int i = tid; i < kVecsF4; i += NT) vecs[i] = P[vecs_source(i)];
     // ---- embedding + position embedding -> bufA   (model.py:157-158)
-    for (int idx = tid; idx < kTileRows * 16; idx += 512) {
+    for (int idx = tid; idx < TR * 16; idx += NT) {
         const int r = idx >> 4, c4 = idx & 15;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (r < rows_valid) {
@@ -256,7 +261,7 @@ __device__ __forceinline__ void branch_body(const f32x4* __restrict__ P, const u
             const int head_off = 32 * h + (odd ? 16 : 0);
             const float* kp0 = bufA + att_start * kLdsStride + head_off;
             const float* kp1 = bufA + att_start_pair * kLdsStride + head_off;
-            const int v_off = kTileRows * kLdsStride;       // bufB = bufA + v_off
+            const int v_off = TR * kLdsStride;       // bufB = bufA + v_off
             float sm[2], sr[2];                             // softmax statistics: not needed for scoring
             if (__builtin_amdgcn_ballot_w64(att_start != att_start_pair) == 0) {
                 attend<W, 2>(kp0, kp0 + v_off, q, o, sm, sr);
@@ -366,7 +371,7 @@ __device__ __forceinline__ void branch_body(const f32x4* __restrict__ P, const u
         for (int u = 0; u < 8; ++u) *reinterpret_cast<f32x4*>(xb + 8 * u) = x1[u];
         if (h == 0) score[row] = ew;
         __syncthreads();
-        for (int oi = tid; oi < sites_here * 64; oi += 512) {
+        for (int oi = tid; oi < sites_here * 64; oi += NT) {
             const int s = oi >> 6, f = oi & 63;
             const float* sp = score + s * W;
             const float* xp = bufA + (s * W) * kLdsStride + f;
@@ -799,20 +804,27 @@ struct Front5Args {
     Branch3Args br;
     DenseArgs strct, esm1;
 };
-__global__ __launch_bounds__(512) void front5_kernel(Front5Args p) {
+constexpr int kSmallTileRows = 64;      // two wavefronts: one site of 51 or 33 rows, three of 21
+constexpr int64_t kSmallTileSites = 192; // calls up to this many sites take them: 2n + n/3 two-wavefront workgroups, at most two
+                                         // per CU, so every wavefront still has a SIMD to itself (measured: 53 sites 120 us
+                                         // against 190 with eight-wavefront tiles, 160 sites 131 against 197, 220 sites 203 against 197)
+__global__ __launch_bounds__(2 * kSmallTileRows) void front5_kernel(Front5Args p) {
     extern __shared__ __attribute__((aligned(16))) float lds_front[];
+    constexpr int TR = kSmallTileRows;
     if (blockIdx.y == 0) {
-        if ((int64_t)blockIdx.x * (kTileRows / 51) < p.br.n_sites) branch_body<51>(p.br.P[2], p.br.tok[2], p.br.n_sites, p.br.out, p.br.ldo, 2 * kD);
+        if ((int64_t)blockIdx.x * (TR / 51) < p.br.n_sites) branch_body<51, TR>(p.br.P[2], p.br.tok[2], p.br.n_sites, p.br.out, p.br.ldo, 2 * kD);
     } else if (blockIdx.y == 1) {
-        if ((int64_t)blockIdx.x * (kTileRows / 33) < p.br.n_sites) branch_body<33>(p.br.P[1], p.br.tok[1], p.br.n_sites, p.br.out, p.br.ldo, kD);
-    } else if (blockIdx.y == 2) {
-        if ((int64_t)blockIdx.x * (kTileRows / 21) < p.br.n_sites) branch_body<21>(p.br.P[0], p.br.tok[0], p.br.n_sites, p.br.out, p.br.ldo, 0);
+        if ((int64_t)blockIdx.x * (TR / 33) < p.br.n_sites) branch_body<33, TR>(p.br.P[1], p.br.tok[1], p.br.n_sites, p.br.out, p.br.ldo, kD);
     } else {
-        const DenseArgs& d = blockIdx.y == 3 ? p.strct : p.esm1;
-        const int ctiles = d.n_pad >> 5, rtiles = (int)((d.m + 31) >> 5);
-        if ((int)blockIdx.x < ctiles * rtiles)
-            dense_small_body<kEpiSwishAffine>(d, reinterpret_cast<float (*)[16][64]>(lds_front), (int)blockIdx.x / ctiles, (int)blockIdx.x % ctiles);
+        if ((int64_t)blockIdx.x * (TR / 21) < p.br.n_sites) branch_body<21, TR>(p.br.P[0], p.br.tok[0], p.br.n_sites, p.br.out, p.br.ldo, 0);
     }
+}
+// the structure layer (grid.y = 0) and the first ESM layer (grid.y = 1) of a small call in one launch
+__global__ __launch_bounds__(512) void dense2_small_kernel(DenseArgs a0, DenseArgs a1) {
+    __shared__ float part[8][16][64];
+    const DenseArgs& d = blockIdx.y == 0 ? a0 : a1;
+    const int ctiles = d.n_pad >> 5, rtiles = (int)((d.m + 31) >> 5);
+    if ((int)blockIdx.x < ctiles * rtiles) dense_small_body<kEpiSwishAffine>(d, part, (int)blockIdx.x / ctiles, (int)blockIdx.x % ctiles);
 }
 
 // ------------------------------------------------------------------------------------ launchers
@@ -877,24 +889,15 @@ hipError_t launch_branch3(const float* const (&params)[3], const uint8_t* const 
     return hipGetLastError();
 }
 
-static hipError_t front5_attr(int dev) {
-    static bool attr_done_dev[64] = {};
-    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (attr_done_dev[dev]) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&front5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)kBranchLds);
-    if (e == hipSuccess) attr_done_dev[dev] = true;
-    return e;
-}
+static constexpr size_t kFrontLds = (2 * kSmallTileRows * kLdsStride + kSmallTileRows) * sizeof(float) + kVecsF4 * 16;
+static_assert(kFrontLds <= 64 * 1024, "the small tile needs no LDS opt-in");
 
+// The front of a small call: the three branches in two-wavefront tiles (one launch, grid.y = branch) and, next to it in
+// a second launch on the same stream -- the first leaves most CUs idle -- the structure and first ESM layers.
 hipError_t launch_front5(const float* const (&params)[3], const uint8_t* const (&tok)[3], int64_t n, float* out, int ldo,
                          const DenseArgs& strct, const DenseArgs& esm1, hipStream_t st) {
     if (n <= 0) return hipSuccess;
     if (strct.m != n || esm1.m != n || n > kDenseSmallRows || strct.n_pad % 32 != 0 || esm1.n_pad % 32 != 0) return hipErrorInvalidValue;
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if ((e = front5_attr(dev)) != hipSuccess) return e;
     Front5Args p;
     for (int b = 0; b < 3; ++b) {
         p.br.P[b] = reinterpret_cast<const f32x4*>(params[b]);
@@ -903,14 +906,25 @@ hipError_t launch_front5(const float* const (&params)[3], const uint8_t* const (
     p.br.n_sites = n;
     p.br.out = out;
     p.br.ldo = ldo;
-    p.strct = strct;
-    p.esm1 = esm1;
-    constexpr int S51 = kTileRows / 51;
     const int64_t rtiles = (n + 31) / 32;
-    int64_t gx = (n + S51 - 1) / S51;
-    gx = std::max<int64_t>(gx, rtiles * (strct.n_pad / 32));
-    gx = std::max<int64_t>(gx, rtiles * (esm1.n_pad / 32));
-    hipLaunchKernelGGL(front5_kernel, dim3((unsigned)gx, 5), dim3(512), kBranchLds, st, p);
+    const int64_t gd = std::max<int64_t>(rtiles * (strct.n_pad / 32), rtiles * (esm1.n_pad / 32));
+    hipLaunchKernelGGL(dense2_small_kernel, dim3((unsigned)gd, 2), dim3(512), 0, st, strct, esm1);
+    static const int64_t small_tile_sites = [] {
+        const char* e = std::getenv("DPTM_SMALL_TILE_SITES");
+        return e ? (int64_t)std::atoll(e) : kSmallTileSites;
+    }();
+    if (n <= small_tile_sites) {
+        // one site per tile for W = 51 and 33 (the most tiles), three for W = 21
+        hipLaunchKernelGGL(front5_kernel, dim3((unsigned)n, 3), dim3(2 * kSmallTileRows), kFrontLds, st, p);
+        return hipGetLastError();
+    }
+    // more sites than two-wavefront tiles have SIMDs to themselves: the eight-wavefront tiles
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if ((e = branch3_attr(dev)) != hipSuccess) return e;
+    constexpr int S51 = kTileRows / 51;
+    hipLaunchKernelGGL(branch3_kernel, dim3((unsigned)((n + S51 - 1) / S51), 3), dim3(512), kBranchLds, st, p.br);
     return hipGetLastError();
 }
 
@@ -981,7 +995,6 @@ hipError_t prepare_kernels() {
     if ((e = branch_attr<21>(dev)) != hipSuccess) return e;
     if ((e = branch_attr<33>(dev)) != hipSuccess) return e;
     if ((e = branch_attr<51>(dev)) != hipSuccess) return e;
-    if ((e = front5_attr(dev)) != hipSuccess) return e;
     return branch3_attr(dev);
 }
 

@@ -45,7 +45,9 @@ def test_golden_fixture(model, golden_dir):
     assert np.array_equal((p[:, 1] >= 0.5)[far], (g["proba"][:, 1] >= 0.5)[far])
 
 
-@pytest.mark.parametrize("n", [1, 2, 5, 7, 12, 13, 64, 257, 1000])
+# 53, 192 | 193: the two-wavefront tiles of small calls (one site per workgroup) and their switch to eight-wavefront tiles;
+# 512 | 513: the small-call dense kernels and the throughput ones
+@pytest.mark.parametrize("n", [1, 2, 5, 7, 12, 13, 53, 64, 192, 193, 257, 512, 513, 1000])
 def test_ragged_sizes_vs_oracle(model, weights, n):
     x = spec.synthetic_inputs(n, 1000 + n)
     p = model.predict(x)
@@ -95,6 +97,20 @@ def test_rows_independent_and_ordered(model):
     tail = model.predict([a[-1000:] for a in x])
     assert np.array_equal(tail, p[-1000:])
     assert np.isfinite(p).all() and np.abs(p.sum(axis=1) - 1).max() < 1e-6
+
+
+def test_small_calls_of_either_tile_agree_bit_for_bit(model):
+    """Calls of up to 512 sites share the dense kernels and differ only in the tile of the sequence branches (two
+    wavefronts up to 192 sites, eight beyond): a site scores the same bits in either, wherever it sits in the call."""
+    x = spec.synthetic_inputs(400, 91)
+    big = model.predict(x)                              # eight-wavefront tiles
+    for lo, hi in ((0, 150), (37, 229), (399, 400), (208, 400)):
+        small = model.predict([a[lo:hi] for a in x])    # two-wavefront tiles (the 192-site ones at most)
+        assert np.array_equal(small, big[lo:hi]), (lo, hi)
+    dev = [a for a in x]
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(150)
+    assert np.array_equal(model.predict([a[:150][perm] for a in dev]), big[:150][perm])
 
 
 def test_full_size_is_periodic_and_matches_oracle(model, weights):
