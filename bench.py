@@ -21,6 +21,7 @@ Also reported on the same line (N = 1):
                timed on a bounded sample of the same workload on the host cores.
   variants     the other arithmetic modes on the same resident inputs.
   streamed_from_host  the same model with NumPy arrays in and out (PCIe included).
+  small_call   latency of one 53-site call (the reference's own use), host arrays and device-resident.
   proteome     many small proteins per call through dptm_score_proteins_device: window
                assembly + ESM row gather on the device (BASELINE north_star 1 and 4).
   sweep        BASELINE config 4 on one GPU: 17 weight sets over 262,144 resident sites (every site of every type
@@ -640,6 +641,47 @@ def measure_streamed(model, n: int) -> dict:
             "note": "host arrays in, host arrays out (Model.predict): pinned double-buffered pipeline"}
 
 
+def measure_small_call(model, sc, dev, n: int = 53) -> dict:
+    """Latency of ONE small call -- the reference's own use: the 53 S/T sites of a 480-residue protein per
+    model.predict (predict.py:598-599) -- with host arrays in and out, and device-resident (enqueue + wait, and
+    back to back without waiting in between = device time per call)."""
+    from deepptmpred_amd import spec
+    hx = spec.synthetic_inputs(n, 79)
+    for _ in range(5):
+        p = model.predict(hx)
+    assert p.shape == (n, 2) and np.isfinite(p).all()
+    t = []
+    for _ in range(100):
+        t0 = time.perf_counter()
+        model.predict(hx)
+        t.append(time.perf_counter() - t0)
+    host_us = sorted(t)[50] * 1e6
+    d = [torch.from_numpy(a).to(dev) for a in hx]
+    out = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    call = lambda: sc.score_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), n,
+                                   out.data_ptr(), 0)
+    for _ in range(5):
+        call()
+    sc.sync()
+    t = []
+    for _ in range(100):
+        t0 = time.perf_counter()
+        call()
+        sc.sync()
+        t.append(time.perf_counter() - t0)
+    dev_us = sorted(t)[50] * 1e6
+    t0 = time.perf_counter()
+    for _ in range(300):
+        call()
+    sc.sync()
+    b2b_us = (time.perf_counter() - t0) / 300 * 1e6
+    assert np.abs(out.cpu().numpy() - p).max() < 1e-6
+    return {"sites": n, "host_arrays_us_per_call": host_us, "device_resident_us_per_call": dev_us,
+            "device_resident_back_to_back_us_per_call": b2b_us,
+            "note": "median of 100 calls; back to back = 300 calls enqueued without waiting in between"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--types", type=int, default=0,
@@ -763,6 +805,7 @@ def main() -> None:
                 return {"error": f"{type(e).__name__}: {e}"}
 
         extras["streamed_from_host"] = guarded(measure_streamed, model, min(n, 262144))
+        extras["small_call"] = guarded(measure_small_call, model, sc, R.dev)
         extras["proteome"] = guarded(measure_proteome, R, sc, 20000 if n >= 262144 else 200, 3, 1)
         ns = min(n, 262144)
         xs = [t[:ns] for t in x]
