@@ -929,14 +929,21 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
     bool merged3 = merge_allowed && !t->serial && !t->prof_on && !t->ar_fn;
     const int nw3 = t_tile_cfg(B, kW[2]).NW;
     int64_t wgs3 = 0;
+    bool one_site_tiles = true;
     for (int b = 0; b < 3 && merged3; ++b) {
         const TileCfg tcb = t_tile_cfg(B, kW[b]);
         merged3 = tcb.NW == nw3 && (nw3 == 4 || nw3 == 8) && part_sums_deferred(tcb.ntiles);
         wgs3 += tcb.ntiles;
+        one_site_tiles = one_site_tiles && tcb.S == 1;
     }
     // ... while all their workgroups are on the chip at once (measured: 512 sites 1.35 -> 1.18 ms; beyond one round of
     // workgroups -- 768, 1,280 sites -- three streams that take turns on the CUs are the faster form again)
-    merged3 = merged3 && wgs3 <= 232;      // (a little short of the 256 CUs: the per-site lane needs some too)
+    static const int64_t merge_wgs = [] {
+        const char* e = std::getenv("DPTM_TRAIN_MERGE_WGS");    // (measurements: another limit)
+        return e ? std::atoll(e) : (int64_t)232;                // a little short of the 256 CUs: the per-site lane needs some too
+    }();
+    // (one-site tiles: up to the whole chip -- 85 sites: 0.58 ms in one launch against 0.72 on three streams)
+    merged3 = merged3 && wgs3 <= (one_site_tiles && !std::getenv("DPTM_TRAIN_MERGE_WGS") ? 256 : merge_wgs);
     hipStream_t bstream[3] = {t->serial || merged3 ? st : t->aux[0], t->serial || merged3 ? st : t->aux[1], st};
     hipStream_t ss = !t->serial ? t->aux[2] : st;      // per-site layers that run next to the branches
     hipStream_t side[3] = {bstream[0], bstream[1], ss};

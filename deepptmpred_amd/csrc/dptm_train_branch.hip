@@ -846,12 +846,19 @@ __device__ __forceinline__ void tb_bwd_body(const TbBwdArgs& p) {
 #undef AT1
 }
 
+#include "dptm_train_pair.h"
+
 // ------------------------------------------------------------------------------------ kernels
 
 template <int W>
 __global__ __launch_bounds__(512) void tb_fwd_kernel(TbFwdArgs p) { tb_fwd_body<W>(p); }
 template <int W, int MAXT, int MODE>
 __global__ __launch_bounds__(MAXT) void tb_bwd_kernel(TbBwdArgs p) { tb_bwd_body<W, MAXT, MODE>(p); }
+// one site in four wavefronts (dptm_train_pair.h)
+template <int W>
+__global__ __launch_bounds__(256) void tb_fwd_pair_kernel(TbFwdArgs p) { tb_fwd_pair_body<W>(p); }
+template <int W>
+__global__ __launch_bounds__(256) void tb_bwd_pair_kernel(TbBwdArgs p) { tb_bwd_pair_body<W>(p); }
 
 // The three branches' launch as ONE (grid.y = branch; four-wavefront tiles, a tile per workgroup): see conv_a_fwd3_kernel
 struct TbFwdArgs3 { TbFwdArgs a[3]; };
@@ -875,6 +882,25 @@ __global__ __launch_bounds__(MAXT) void tb_bwd3_kernel(TbBwdArgs3 p) {
         if ((int64_t)blockIdx.x < p.a[1].ntiles) tb_bwd_body<33, MAXT, 0>(p.a[1]);
     } else {
         if ((int64_t)blockIdx.x < p.a[2].ntiles) tb_bwd_body<51, MAXT, 0>(p.a[2]);
+    }
+}
+
+__global__ __launch_bounds__(256) void tb_fwd3_pair_kernel(TbFwdArgs3 p) {
+    if (blockIdx.y == 2) {
+        if ((int64_t)blockIdx.x < p.a[0].ntiles) tb_fwd_pair_body<21>(p.a[0]);
+    } else if (blockIdx.y == 1) {
+        if ((int64_t)blockIdx.x < p.a[1].ntiles) tb_fwd_pair_body<33>(p.a[1]);
+    } else {
+        if ((int64_t)blockIdx.x < p.a[2].ntiles) tb_fwd_pair_body<51>(p.a[2]);
+    }
+}
+__global__ __launch_bounds__(256) void tb_bwd3_pair_kernel(TbBwdArgs3 p) {
+    if (blockIdx.y == 2) {
+        if ((int64_t)blockIdx.x < p.a[0].ntiles) tb_bwd_pair_body<21>(p.a[0]);
+    } else if (blockIdx.y == 1) {
+        if ((int64_t)blockIdx.x < p.a[1].ntiles) tb_bwd_pair_body<33>(p.a[1]);
+    } else {
+        if ((int64_t)blockIdx.x < p.a[2].ntiles) tb_bwd_pair_body<51>(p.a[2]);
     }
 }
 
@@ -1101,12 +1127,27 @@ hipError_t t_reduce_parts(const float* part, int nparts, const PartUnits& u, con
 static size_t fwd_lds(int NW) { return ((size_t)2 * NW * 32 * kLdsStride + 2 * NW * 32 + 128) * sizeof(float); }
 static size_t bwd_lds(int NW) { return ((size_t)2 * img_floats(NW) + kXreg + kTbVecs * 64 + 128) * sizeof(float); }
 
+// A one-site tile of four wavefronts runs the pair kernels (DPTM_TRAIN_PAIR=0: the plain ones, for A/B measurements)
+static bool pair_tile(int S, int NW) {
+    static const bool on = [] {
+        const char* e = std::getenv("DPTM_TRAIN_PAIR");
+        return !(e && e[0] == '0');
+    }();
+    return on && S == 1 && NW == 4;
+}
+
 template <int W>
 static hipError_t launch_fwd(const TbFwdArgs& a, int NW, hipStream_t st) {
-    static bool done[64] = {};
+    static bool done[64] = {}, done_pair[64] = {};
+    const int64_t grid = a.ntiles < 1024 ? a.ntiles : 1024;
+    if (pair_tile(a.S, NW)) {
+        hipError_t e = lds_opt_in(&tb_fwd_pair_kernel<W>, done_pair, fwd_pair_lds());
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(tb_fwd_pair_kernel<W>, dim3((unsigned)grid), dim3(256), fwd_pair_lds(), st, a);
+        return hipGetLastError();
+    }
     hipError_t e = lds_opt_in(&tb_fwd_kernel<W>, done, fwd_lds(8));
     if (e != hipSuccess) return e;
-    const int64_t grid = a.ntiles < 1024 ? a.ntiles : 1024;
     hipLaunchKernelGGL(tb_fwd_kernel<W>, dim3((unsigned)grid), dim3(64 * NW), fwd_lds(NW), st, a);
     return hipGetLastError();
 }
@@ -1123,7 +1164,13 @@ hipError_t t_tb_fwd(const TbFwdArgs& a, int wlen, int NW, hipStream_t st) {
 
 template <int W>
 static hipError_t launch_bwd(const TbBwdArgs& a, int NW, int grid, hipStream_t st) {
-    static bool done[64] = {}, done_small[64] = {};
+    static bool done[64] = {}, done_small[64] = {}, done_pair[64] = {};
+    if (pair_tile(a.S, NW)) {
+        hipError_t e = lds_opt_in(&tb_bwd_pair_kernel<W>, done_pair, bwd_pair_lds());
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(tb_bwd_pair_kernel<W>, dim3((unsigned)grid), dim3(256), bwd_pair_lds(), st, a);
+        return hipGetLastError();
+    }
     if (NW <= 4) {
         hipError_t e = lds_opt_in(&tb_bwd_kernel<W, 256, 0>, done_small, bwd_lds(4));
         if (e != hipSuccess) return e;
@@ -1319,9 +1366,12 @@ static bool tb3_ok(const A (&a)[3], int NW) {
 }
 
 hipError_t t_tb_fwd3(const TbFwdArgs (&a)[3], int NW, hipStream_t st) {
-    static bool d4[64] = {}, d8[64] = {};
+    static bool d4[64] = {}, d8[64] = {}, dp[64] = {};
     if (!tb3_ok(a, NW)) return hipErrorInvalidValue;
-    hipError_t e = NW == 4 ? lds_opt_in(&tb_fwd3_kernel<256>, d4, fwd_lds(4)) : lds_opt_in(&tb_fwd3_kernel<512>, d8, fwd_lds(8));
+    const bool pair = pair_tile(a[0].S, NW) && pair_tile(a[1].S, NW) && pair_tile(a[2].S, NW);
+    hipError_t e = pair      ? lds_opt_in(&tb_fwd3_pair_kernel, dp, fwd_pair_lds())
+                   : NW == 4 ? lds_opt_in(&tb_fwd3_kernel<256>, d4, fwd_lds(4))
+                             : lds_opt_in(&tb_fwd3_kernel<512>, d8, fwd_lds(8));
     if (e != hipSuccess) return e;
     TbFwdArgs3 p;
     int64_t gx = 1;
@@ -1329,7 +1379,9 @@ hipError_t t_tb_fwd3(const TbFwdArgs (&a)[3], int NW, hipStream_t st) {
         p.a[b] = a[b];
         gx = a[b].ntiles > gx ? a[b].ntiles : gx;
     }
-    if (NW == 4)
+    if (pair)
+        hipLaunchKernelGGL(tb_fwd3_pair_kernel, dim3((unsigned)gx, 3), dim3(256), fwd_pair_lds(), st, p);
+    else if (NW == 4)
         hipLaunchKernelGGL(tb_fwd3_kernel<256>, dim3((unsigned)gx, 3), dim3(256), fwd_lds(4), st, p);
     else
         hipLaunchKernelGGL(tb_fwd3_kernel<512>, dim3((unsigned)gx, 3), dim3(512), fwd_lds(8), st, p);
@@ -1337,9 +1389,12 @@ hipError_t t_tb_fwd3(const TbFwdArgs (&a)[3], int NW, hipStream_t st) {
 }
 
 hipError_t t_tb_bwd3(const TbBwdArgs (&a)[3], const TbGrads (&g)[3], int NW, PartPlan (&plan)[3], hipStream_t st) {
-    static bool d4[64] = {}, d8[64] = {};
+    static bool d4[64] = {}, d8[64] = {}, dp[64] = {};
     if (!tb3_ok(a, NW)) return hipErrorInvalidValue;
-    hipError_t e = NW == 4 ? lds_opt_in(&tb_bwd3_kernel<256>, d4, bwd_lds(4)) : lds_opt_in(&tb_bwd3_kernel<512>, d8, bwd_lds(8));
+    const bool pair = pair_tile(a[0].S, NW) && pair_tile(a[1].S, NW) && pair_tile(a[2].S, NW);
+    hipError_t e = pair      ? lds_opt_in(&tb_bwd3_pair_kernel, dp, bwd_pair_lds())
+                   : NW == 4 ? lds_opt_in(&tb_bwd3_kernel<256>, d4, bwd_lds(4))
+                             : lds_opt_in(&tb_bwd3_kernel<512>, d8, bwd_lds(8));
     if (e != hipSuccess) return e;
     TbBwdArgs3 p;
     int64_t gx = 1;
@@ -1349,7 +1404,9 @@ hipError_t t_tb_bwd3(const TbBwdArgs (&a)[3], const TbGrads (&g)[3], int NW, Par
         gx = a[b].ntiles > gx ? a[b].ntiles : gx;
         tb_bwd_plan(g[b], &plan[b]);
     }
-    if (NW == 4)
+    if (pair)
+        hipLaunchKernelGGL(tb_bwd3_pair_kernel, dim3((unsigned)gx, 3), dim3(256), bwd_pair_lds(), st, p);
+    else if (NW == 4)
         hipLaunchKernelGGL(tb_bwd3_kernel<256>, dim3((unsigned)gx, 3), dim3(256), bwd_lds(4), st, p);
     else
         hipLaunchKernelGGL(tb_bwd3_kernel<512>, dim3((unsigned)gx, 3), dim3(512), bwd_lds(8), st, p);
