@@ -846,6 +846,7 @@ __device__ __forceinline__ void tb_bwd_body(const TbBwdArgs& p) {
 #undef AT1
 }
 
+#define DPTM_PAIR_TB_BODIES 1
 #include "dptm_train_pair.h"
 
 // ------------------------------------------------------------------------------------ kernels
@@ -1128,7 +1129,7 @@ static size_t fwd_lds(int NW) { return ((size_t)2 * NW * 32 * kLdsStride + 2 * N
 static size_t bwd_lds(int NW) { return ((size_t)2 * img_floats(NW) + kXreg + kTbVecs * 64 + 128) * sizeof(float); }
 
 // A one-site tile of four wavefronts runs the pair kernels (DPTM_TRAIN_PAIR=0: the plain ones, for A/B measurements)
-static bool pair_tile(int S, int NW) {
+bool t_pair_tile(int S, int NW) {
     static const bool on = [] {
         const char* e = std::getenv("DPTM_TRAIN_PAIR");
         return !(e && e[0] == '0');
@@ -1140,7 +1141,7 @@ template <int W>
 static hipError_t launch_fwd(const TbFwdArgs& a, int NW, hipStream_t st) {
     static bool done[64] = {}, done_pair[64] = {};
     const int64_t grid = a.ntiles < 1024 ? a.ntiles : 1024;
-    if (pair_tile(a.S, NW)) {
+    if (t_pair_tile(a.S, NW)) {
         hipError_t e = lds_opt_in(&tb_fwd_pair_kernel<W>, done_pair, fwd_pair_lds());
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(tb_fwd_pair_kernel<W>, dim3((unsigned)grid), dim3(256), fwd_pair_lds(), st, a);
@@ -1165,7 +1166,7 @@ hipError_t t_tb_fwd(const TbFwdArgs& a, int wlen, int NW, hipStream_t st) {
 template <int W>
 static hipError_t launch_bwd(const TbBwdArgs& a, int NW, int grid, hipStream_t st) {
     static bool done[64] = {}, done_small[64] = {}, done_pair[64] = {};
-    if (pair_tile(a.S, NW)) {
+    if (t_pair_tile(a.S, NW)) {
         hipError_t e = lds_opt_in(&tb_bwd_pair_kernel<W>, done_pair, bwd_pair_lds());
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(tb_bwd_pair_kernel<W>, dim3((unsigned)grid), dim3(256), bwd_pair_lds(), st, a);
@@ -1368,7 +1369,7 @@ static bool tb3_ok(const A (&a)[3], int NW) {
 hipError_t t_tb_fwd3(const TbFwdArgs (&a)[3], int NW, hipStream_t st) {
     static bool d4[64] = {}, d8[64] = {}, dp[64] = {};
     if (!tb3_ok(a, NW)) return hipErrorInvalidValue;
-    const bool pair = pair_tile(a[0].S, NW) && pair_tile(a[1].S, NW) && pair_tile(a[2].S, NW);
+    const bool pair = t_pair_tile(a[0].S, NW) && t_pair_tile(a[1].S, NW) && t_pair_tile(a[2].S, NW);
     hipError_t e = pair      ? lds_opt_in(&tb_fwd3_pair_kernel, dp, fwd_pair_lds())
                    : NW == 4 ? lds_opt_in(&tb_fwd3_kernel<256>, d4, fwd_lds(4))
                              : lds_opt_in(&tb_fwd3_kernel<512>, d8, fwd_lds(8));
@@ -1391,7 +1392,7 @@ hipError_t t_tb_fwd3(const TbFwdArgs (&a)[3], int NW, hipStream_t st) {
 hipError_t t_tb_bwd3(const TbBwdArgs (&a)[3], const TbGrads (&g)[3], int NW, PartPlan (&plan)[3], hipStream_t st) {
     static bool d4[64] = {}, d8[64] = {}, dp[64] = {};
     if (!tb3_ok(a, NW)) return hipErrorInvalidValue;
-    const bool pair = pair_tile(a[0].S, NW) && pair_tile(a[1].S, NW) && pair_tile(a[2].S, NW);
+    const bool pair = t_pair_tile(a[0].S, NW) && t_pair_tile(a[1].S, NW) && t_pair_tile(a[2].S, NW);
     hipError_t e = pair      ? lds_opt_in(&tb_bwd3_pair_kernel, dp, bwd_pair_lds())
                    : NW == 4 ? lds_opt_in(&tb_bwd3_kernel<256>, d4, bwd_lds(4))
                              : lds_opt_in(&tb_bwd3_kernel<512>, d8, bwd_lds(8));

@@ -24,17 +24,21 @@
 
 namespace dptm {
 
+#include "dptm_train_pair.h"
+
 namespace {
 
 // acc += w0^T x[r0] + w1^T x[r1] + w2^T x[r2] for three packed 64 x 64 matrices and three rows of an LDS image
 // (pointers already at the lane's half: + 4h); rows r0 / r2 count only where ok0 / ok2 (pass any valid address otherwise)
-__device__ __forceinline__ void taps3(f32x16 (&acc)[2], const f32x4* __restrict__ w0, const f32x4* __restrict__ w1,
+// (NT output tiles from tile 0 of the matrices on: a caller that wants one tile passes the matrices at that tile)
+template <int NT>
+__device__ __forceinline__ void taps3(f32x16 (&acc)[NT], const f32x4* __restrict__ w0, const f32x4* __restrict__ w1,
                                       const f32x4* __restrict__ w2, const float* r0, const float* r1, const float* r2, bool ok0,
                                       bool ok2, int lane) {
-    f32x4 a0[2][2], a1[2][2], a2[2][2], b0[2], b1[2], b2[2];
+    f32x4 a0[2][NT], a1[2][NT], a2[2][NT], b0[2], b1[2], b2[2];
     auto fetch = [&](int u, int s) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < NT; ++t) {
             a0[s][t] = w0[(t * 8 + u) * 64 + lane];
             a1[s][t] = w1[(t * 8 + u) * 64 + lane];
             a2[s][t] = w2[(t * 8 + u) * 64 + lane];
@@ -53,7 +57,7 @@ __device__ __forceinline__ void taps3(f32x16 (&acc)[2], const f32x4* __restrict_
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < NT; ++t) {
                 mfma(acc[t], a0[s][t][e], b0[s][e]);
                 mfma(acc[t], a1[s][t][e], b1[s][e]);
                 mfma(acc[t], a2[s][t][e], b2[s][e]);
@@ -557,6 +561,353 @@ __device__ __forceinline__ void conv_a_bwd_body(const ConvArgs& p) {
     for (int i = tid; i < 128; i += blockDim.x) part[kCaVec + i] = vacc[i];
 }
 
+
+// ------------------------------------------------------------------------------------ one-site tiles (dptm_train_pair.h)
+
+// The same four kernels for ONE site in FOUR wavefronts: wavefronts w and w + 2 share row block w & 1, each with one
+// of the two output tiles of every product, its half of every image row and the column sums of its own 32 features.
+// A convolution reads whole rows of the LDS image, so the halves need no exchange here.
+
+namespace {
+// own groups of bn_swish_backward
+__device__ __forceinline__ void bn_swish_backward4(const f32x4 (&a)[4], const f32x4 (&dz)[4], const float* bb, int h, int part,
+                                                   bool row_ok, f32x4 (&da)[4]) {
+    bb += 32 * part + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c = 8 * g;
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(bb + c), inv = *reinterpret_cast<const f32x4*>(bb + 64 + c);
+        const f32x4 gi = *reinterpret_cast<const f32x4*>(bb + 128 + c), s1 = *reinterpret_cast<const f32x4*>(bb + 192 + c);
+        const f32x4 s2 = *reinterpret_cast<const f32x4*>(bb + 256 + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = a[g][e];
+            const float sg = fast_rcp(1.0f + __expf(-v));
+            const float xh = (v * sg - mu[e]) * inv[e];
+            const float dy = gi[e] * (dz[g][e] - s1[e] - xh * s2[e]);
+            da[g][e] = row_ok ? dy * (sg * (1.0f + v * (1.0f - sg))) : 0.f;
+        }
+    }
+}
+// z = BN(swish(a)) of the own groups; zero on padding rows
+__device__ __forceinline__ void bn_swish4(const f32x4 (&a)[4], const float* bnv, int h, int part, bool row_ok, f32x4 (&z)[4]) {
+    bnv += 32 * part + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(bnv + 8 * g);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(bnv + 64 + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[g][e] = row_ok ? fmaf(swishf(a[g][e]), sc[e], sh[e]) : 0.f;
+    }
+}
+// swish of the own groups and its column sums [sum | sum of squares] over the wavefront's rows, added to sacc[128]
+__device__ __forceinline__ void swish_sums4(f32x4 (&t)[4], bool row_ok, float* mine_b, float* own_b, int h, int part, int lane,
+                                            float* sacc) {
+    f32x4 y2[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            t[g][e] = row_ok ? swishf(t[g][e]) : 0.f;
+            y2[g][e] = t[g][e] * t[g][e];
+        }
+    chain_store4(mine_b, h, part, t);
+    wave_fence();
+    const float c1 = colsum_rows_own(own_b, part, lane);
+    wave_fence();
+    chain_store4(mine_b, h, part, y2);
+    wave_fence();
+    const float c2 = colsum_rows_own(own_b, part, lane);
+    wave_fence();
+    if (lane < 32) {
+        atomicAdd(&sacc[32 * part + lane], c1);
+        atomicAdd(&sacc[64 + 32 * part + lane], c2);
+    }
+}
+}  // namespace
+
+#define DPTM_PAIR_SETUP                                                                                      \
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);            \
+    const int pw = wave & 1, part = wave >> 1;                                                               \
+    const int h = lane >> 5, j = lane & 31;                                                                  \
+    const unsigned seed = p.step[kStepSeed];                                                                 \
+    const int row = pw * 32 + j;                                                                             \
+    const bool row_ok = row < W;                                                                             \
+    const bool tap0_ok = row_ok && row > 0, tap2_ok = row_ok && row < W - 1;                                 \
+    float* own_a = bufA + pw * 32 * kLdsStride;                                                              \
+    float* own_b = bufB + pw * 32 * kLdsStride;                                                              \
+    float* mine_a = own_a + j * kLdsStride;                                                                  \
+    float* mine_b = own_b + j * kLdsStride;                                                                  \
+    const f32x4* cv = p.P + kOffConvV + 4 * part;       /* the own groups of a packed 64-feature vector */     \
+    (void)seed; (void)own_a; (void)mine_a; (void)cv; (void)tap0_ok; (void)tap2_ok
+
+template <int W>
+__device__ __forceinline__ void conv_a_fwd_pair_body(const ConvArgs& p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* bufA = lds;
+    float* bufB = bufA + kPairImg;
+    float* sacc = bufB + kPairImg;     // [sum | sum of squares] of swish(a1), this workgroup
+    DPTM_PAIR_SETUP;
+    for (int i = tid; i < 128; i += blockDim.x) sacc[i] = 0.f;
+#pragma unroll 1
+    for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int64_t co = ((tile * 4 + pw) * 8 + 4 * part) * 64 + lane;      // the wavefront's own groups
+        __syncthreads();   // the previous tile's image has been read
+        embed_tile<W>(p, bufA, 64, W, tile, seed);
+        __syncthreads();
+        const float* xc = bufA + row * kLdsStride + 4 * h;
+        f32x16 acc[1];
+        f32x4 t[4];
+        {
+            f32x4 x0[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x0[u] = *reinterpret_cast<const f32x4*>(xc + 8 * u);
+            acc_init_bias<1>(acc, cv + kVScB * kVec64, h, 8);
+            gemm_regs<8, 1>(acc, p.P + kOffScW + part * 8 * 64, x0, lane);
+            acc_to_x<1>(acc, t);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) p.cs.s[co + g * 64] = t[g];
+        }
+        acc_init_bias<1>(acc, cv + kVC3aB * kVec64, h, 8);
+        const f32x4* wt = p.P + kOffC3aW + part * 8 * 64;
+        taps3<1>(acc, wt, wt + kMat64, wt + 2 * kMat64, tap0_ok ? xc - kLdsStride : xc, xc, tap2_ok ? xc + kLdsStride : xc, tap0_ok,
+                 tap2_ok, lane);
+        acc_to_x<1>(acc, t);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) p.cs.a1[co + g * 64] = t[g];
+        swish_sums4(t, row_ok, mine_b, own_b, h, part, lane, sacc);
+    }
+    __syncthreads();
+    for (int i = tid; i < 128; i += blockDim.x) atomicAdd(p.stats1 + i, sacc[i]);
+}
+
+template <int W>
+__device__ __forceinline__ void conv_b_fwd_pair_body(const ConvArgs& p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* bufA = lds;
+    float* bufB = bufA + kPairImg;
+    float* sacc = bufB + kPairImg;
+    float* bnv = sacc + 128;
+    DPTM_PAIR_SETUP;
+    for (int i = tid; i < 128; i += blockDim.x) sacc[i] = 0.f;
+    bn_prepare(p.bn1, bnv, tid, blockIdx.x == 0);
+#pragma unroll 1
+    for (int64_t tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int64_t co = ((tile * 4 + pw) * 8 + 4 * part) * 64 + lane;
+        __syncthreads();   // the previous tile's image has been read (and bnv is ready)
+        {
+            f32x4 a[4], z[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) a[g] = p.cs.a1[co + g * 64];
+            bn_swish4(a, bnv, h, part, row_ok, z);
+            dropout4(z, tile, h, part, seed, p.stream_conv, p.thr_conv, p.scale_conv);   // one mask value per (site, channel)
+            chain_store4(mine_a, h, part, z);
+        }
+        __syncthreads();
+        const float* xc = mine_a + 4 * h;
+        f32x16 acc[1];
+        acc_init_bias<1>(acc, cv + kVC3bB * kVec64, h, 8);
+        const f32x4* wt = p.P + kOffC3bW + part * 8 * 64;
+        taps3<1>(acc, wt, wt + kMat64, wt + 2 * kMat64, tap0_ok ? xc - kLdsStride : xc, xc, tap2_ok ? xc + kLdsStride : xc, tap0_ok,
+                 tap2_ok, lane);
+        f32x4 t[4];
+        acc_to_x<1>(acc, t);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) p.cs.a2[co + g * 64] = t[g];
+        swish_sums4(t, row_ok, mine_b, own_b, h, part, lane, sacc);
+    }
+    __syncthreads();
+    for (int i = tid; i < 128; i += blockDim.x) atomicAdd(p.stats2 + i, sacc[i]);
+}
+
+template <int W>
+__device__ __forceinline__ void conv_b_bwd_pair_body(const ConvArgs& p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* bufA = lds;
+    float* bufB = bufA + kPairImg;
+    float* bb = bufB + kPairImg;        // [5][64] BN2 backward coefficients
+    float* bnv = bb + 320;              // [2][64] BN1 forward scale | shift
+    float* vacc = bnv + 128;            // [3][64]: conv3b bias gradient, sum d(z1), sum d(z1)*swish(a1)
+    int* tile_slot = reinterpret_cast<int*>(vacc + 192);
+    DPTM_PAIR_SETUP;
+    float* pbuf = p.part + (size_t)blockIdx.x * kTbPartStride + kCbBase;
+    for (int i = tid; i < 192; i += blockDim.x) vacc[i] = 0.f;
+    bn_bwd_prepare(p.bb2, bb, tid, blockIdx.x == 0);
+    {
+        BnFwd f{p.bb1.stats, p.bb1.inv_rows, p.bb1.gamma, p.bb1.beta, nullptr, nullptr};
+        bn_prepare(f, bnv, tid, false);
+    }
+    bool first = true;
+    int tile_round = 0;
+#pragma unroll 1
+    for (int64_t tile = next_tile(p.queue_b, tile_slot, tile_round); tile < p.ntiles; tile = next_tile(p.queue_b, tile_slot, tile_round)) {
+        const int64_t co = ((tile * 4 + pw) * 8 + 4 * part) * 64 + lane;
+        __syncthreads();   // vectors ready; the previous tile's images have been read
+        {
+            // d(a2) -> image B, z1 (the convolution's input) -> image A
+            f32x4 a[4], dz[4], da[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                a[g] = p.cs.a2[co + g * 64];
+                dz[g] = p.dx1[co + g * 64];
+            }
+            bn_swish_backward4(a, dz, bb, h, part, row_ok, da);
+            chain_store4(mine_b, h, part, da);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) a[g] = p.cs.a1[co + g * 64];
+            bn_swish4(a, bnv, h, part, row_ok, dz);
+            dropout4(dz, tile, h, part, seed, p.stream_conv, p.thr_conv, p.scale_conv);
+            chain_store4(mine_a, h, part, dz);
+            wave_fence();
+            const float c = colsum_rows_own(own_b, part, lane);
+            if (lane < 32) atomicAdd(&vacc[32 * part + lane], c);
+        }
+        __syncthreads();
+        // d(z1)[r] = sum_t d(a2)[r - (t-1)] K[t]^T: tap 0 meets row r+1, tap 2 row r-1
+        f32x4 dz1[4];
+        {
+            const float* xc = mine_b + 4 * h;
+            f32x16 acc[1];
+            acc_zero<1>(acc);
+            const f32x4* wt = p.PT + kBtC3bT + part * 8 * 64;
+            taps3<1>(acc, wt, wt + 1024, wt + 2048, tap2_ok ? xc + kLdsStride : xc, xc, tap0_ok ? xc - kLdsStride : xc, tap2_ok, tap0_ok,
+                     lane);
+            acc_to_x<1>(acc, dz1);
+            dropout4(dz1, tile, h, part, seed, p.stream_conv, p.thr_conv, p.scale_conv);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) p.dz1[co + g * 64] = dz1[g];
+            // (the tile's two other 32-row slots are padding: the next kernel expects zeros there)
+            const f32x4 zero4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) p.dz1[co + 2 * 512 + g * 64] = zero4;
+        }
+        // dK[t] += shift_{t-1}(z1)^T d(a2)
+        dw_unit_tap<W, true>(bufA, bufB, -1, 4, nullptr, pbuf + 0 * 4096, first, lane, wave, W);
+        dw_unit<true>(bufA, bufB, 4, nullptr, pbuf + 1 * 4096, first, lane, wave, W);
+        dw_unit_tap<W, true>(bufA, bufB, +1, 4, nullptr, pbuf + 2 * 4096, first, lane, wave, W);
+        // column sums for BN1's backward pass: d(z1) and d(z1) * swish(a1), through the wavefront's own part of the images
+        {
+            f32x4 t[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 a1 = p.cs.a1[co + g * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[g][e] = dz1[g][e] * swishf(a1[e]);
+            }
+            chain_store4(mine_a, h, part, dz1);
+            chain_store4(mine_b, h, part, t);
+            wave_fence();
+            const float c1 = colsum_rows_own(own_a, part, lane), c2 = colsum_rows_own(own_b, part, lane);
+            if (lane < 32) {
+                atomicAdd(&vacc[64 + 32 * part + lane], c1);
+                atomicAdd(&vacc[128 + 32 * part + lane], c2);
+            }
+            wave_fence();
+        }
+        first = false;
+    }
+    __syncthreads();
+    if (first) zero_floats(pbuf, 3 * 4096);
+    for (int i = tid; i < 192; i += blockDim.x) {
+        if (i < 64)
+            pbuf[kCbVec + i] = vacc[i];
+        else
+            atomicAdd(p.bn1_sums + i - 64, vacc[i]);
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void conv_a_bwd_pair_body(const ConvArgs& p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* bufA = lds;
+    float* bufB = bufA + kPairImg;
+    float* bb = bufB + kPairImg;        // [5][64] BN1 backward coefficients
+    float* vacc = bb + 320;             // [2][64]: conv3a bias gradient, shortcut bias gradient
+    int* tile_slot = reinterpret_cast<int*>(vacc + 128);
+    DPTM_PAIR_SETUP;
+    float* pbuf = p.part + (size_t)blockIdx.x * kTbPartStride + kCaBase;
+    for (int i = tid; i < 128; i += blockDim.x) vacc[i] = 0.f;
+    bn_bwd_prepare(p.bb1, bb, tid, blockIdx.x == 0);
+    bool first = true;
+    int tile_round = 0;
+#pragma unroll 1
+    for (int64_t tile = next_tile(p.queue_a, tile_slot, tile_round); tile < p.ntiles; tile = next_tile(p.queue_a, tile_slot, tile_round)) {
+        const int64_t ct = ((tile * 4 + pw) * 8) * 64 + lane;
+        const int64_t co = ct + 4 * part * 64;
+        __syncthreads();
+        embed_tile<W>(p, bufA, 64, W, tile, seed);   // x0 -> image A
+        {
+            f32x4 a[4], dz[4], da[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                a[g] = p.cs.a1[co + g * 64];
+                dz[g] = p.dz1[co + g * 64];
+            }
+            bn_swish_backward4(a, dz, bb, h, part, row_ok, da);
+            chain_store4(mine_b, h, part, da);                        // d(a1) -> image B
+            wave_fence();
+            const float c = colsum_rows_own(own_b, part, lane);
+            if (lane < 32) atomicAdd(&vacc[32 * part + lane], c);
+        }
+        __syncthreads();
+        // d(x0) = sum_t d(a1)[r - (t-1)] K3a[t]^T + d(x1) Ksc^T, this wavefront's output tile
+        f32x16 acc[1];
+        acc_zero<1>(acc);
+        {
+            const float* xc = mine_b + 4 * h;
+            const f32x4* wt = p.PT + kBtC3aT + part * 8 * 64;
+            taps3<1>(acc, wt, wt + 1024, wt + 2048, tap2_ok ? xc + kLdsStride : xc, xc, tap0_ok ? xc - kLdsStride : xc, tap2_ok, tap0_ok,
+                     lane);
+        }
+        dw_unit_tap<W, true>(bufA, bufB, -1, 4, nullptr, pbuf + 0 * 4096, first, lane, wave, W);
+        dw_unit<true>(bufA, bufB, 4, nullptr, pbuf + 1 * 4096, first, lane, wave, W);
+        dw_unit_tap<W, true>(bufA, bufB, +1, 4, nullptr, pbuf + 2 * 4096, first, lane, wave, W);
+        f32x4 dx0[4];
+        {
+            f32x4 d1[8], d4[4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) d1[u] = p.dx1[ct + u * 64];   // zero on padding rows
+            own_groups(d1, part, d4);
+            chain_store4(mine_b, h, part, d4);
+            wave_fence();
+            const float c = colsum_rows_own(own_b, part, lane);
+            if (lane < 32) atomicAdd(&vacc[64 + 32 * part + lane], c);
+            __syncthreads();
+            dw_unit<true>(bufA, bufB, 4, nullptr, pbuf + 3 * 4096, first, lane, wave, W);       // dKsc += x0^T d(x1)
+            gemm_regs<8, 1>(acc, p.PT + kBtScT + part * 8 * 64, d1, lane);
+            acc_to_x<1>(acc, dx0);
+        }
+        dropout4(dx0, tile, h, part, seed, p.stream_embed, p.thr_embed, p.scale_embed);
+        // embedding tables: dP[pos] += the row at that position, dE[code] += rows with that code (one more
+        // weight-gradient unit, dE = onehot(code)^T d(x0), with the one-hot rows as the X image)
+        chain_store4(mine_b, h, part, dx0);
+        {
+            int code = row_ok ? (int)p.tok[tile * W + row] : -1;
+            code = code > kCodes - 1 ? kCodes - 1 : code;
+            f32x4 oh[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) oh[g][e] = (32 * part + 8 * g + 4 * h + e) == code ? 1.0f : 0.f;
+            chain_store4(mine_a, h, part, oh);      // the x0 image has been read by the shortcut's unit
+        }
+        __syncthreads();   // d(x0) and the one-hot rows of the site are in the images
+        for (int o = tid; o < W * 64; o += blockDim.x) {
+            const int pp = o >> 6, f = o & 63;
+            pbuf[kCaPos + o] = (first ? 0.f : pbuf[kCaPos + o]) + bufB[pp * kLdsStride + f];
+        }
+        dw_unit<true>(bufA, bufB, 4, nullptr, pbuf + 4 * 4096, first, lane, wave, W);          // dE += onehot^T d(x0)
+        first = false;
+    }
+    __syncthreads();
+    if (first) {
+        zero_floats(pbuf, 5 * 4096);
+        zero_floats(pbuf + kCaPos, W * 64);
+    }
+    for (int i = tid; i < 128; i += blockDim.x) pbuf[kCaVec + i] = vacc[i];
+}
+#undef DPTM_PAIR_SETUP
+
 // ------------------------------------------------------------------------------------ kernels
 
 template <int W>
@@ -567,6 +918,15 @@ template <int W, bool SHORT>
 __global__ __launch_bounds__(512) void conv_b_bwd_kernel(ConvArgs p) { conv_b_bwd_body<W, SHORT>(p); }
 template <int W, bool SHORT>
 __global__ __launch_bounds__(512) void conv_a_bwd_kernel(ConvArgs p) { conv_a_bwd_body<W, SHORT>(p); }
+
+template <int W>
+__global__ __launch_bounds__(256) void conv_a_fwd_pair_kernel(ConvArgs p) { conv_a_fwd_pair_body<W>(p); }
+template <int W>
+__global__ __launch_bounds__(256) void conv_b_fwd_pair_kernel(ConvArgs p) { conv_b_fwd_pair_body<W>(p); }
+template <int W>
+__global__ __launch_bounds__(256) void conv_b_bwd_pair_kernel(ConvArgs p) { conv_b_bwd_pair_body<W>(p); }
+template <int W>
+__global__ __launch_bounds__(256) void conv_a_bwd_pair_kernel(ConvArgs p) { conv_a_bwd_pair_body<W>(p); }
 
 // The same launch of the three sequence branches as ONE launch, grid.y = branch (four-wavefront tiles, a tile per
 // workgroup; grid.x = the most tiles a branch has, a workgroup beyond its branch's tiles leaves at once).  A small batch's
@@ -593,7 +953,15 @@ __global__ __launch_bounds__(MAXT) void conv_b_bwd3_kernel(ConvArgs3 p) { DPTM_B
 template <int MAXT>
 __global__ __launch_bounds__(MAXT) void conv_a_bwd3_kernel(ConvArgs3 p) { DPTM_BRANCH3(DPTM_CAB(21), DPTM_CAB(33), DPTM_CAB(51)) }
 
+__global__ __launch_bounds__(256) void conv_a_fwd3_pair_kernel(ConvArgs3 p) { DPTM_BRANCH3(conv_a_fwd_pair_body<21>, conv_a_fwd_pair_body<33>, conv_a_fwd_pair_body<51>) }
+__global__ __launch_bounds__(256) void conv_b_fwd3_pair_kernel(ConvArgs3 p) { DPTM_BRANCH3(conv_b_fwd_pair_body<21>, conv_b_fwd_pair_body<33>, conv_b_fwd_pair_body<51>) }
+__global__ __launch_bounds__(256) void conv_b_bwd3_pair_kernel(ConvArgs3 p) { DPTM_BRANCH3(conv_b_bwd_pair_body<21>, conv_b_bwd_pair_body<33>, conv_b_bwd_pair_body<51>) }
+__global__ __launch_bounds__(256) void conv_a_bwd3_pair_kernel(ConvArgs3 p) { DPTM_BRANCH3(conv_a_bwd_pair_body<21>, conv_a_bwd_pair_body<33>, conv_a_bwd_pair_body<51>) }
+
 // ------------------------------------------------------------------------------------ launchers
+
+static size_t conv_fwd_pair_lds() { return ((size_t)2 * kPairImg + 256) * sizeof(float); }
+static size_t conv_bwd_pair_lds() { return ((size_t)2 * kPairImg + 320 + 128 + 192 + 16) * sizeof(float); }
 
 static size_t conv_fwd_lds(int NW) { return ((size_t)2 * NW * 32 * kLdsStride + 256) * sizeof(float); }
 static size_t conv_bwd_lds(int NW) { return ((size_t)2 * NW * 32 * kLdsStride + kConvLdsExtra) * sizeof(float); }
@@ -629,10 +997,23 @@ static hipError_t launch_conv(K kernel, bool (&done)[64], const ConvArgs& a, int
                                 : launch_conv(&KERNEL<51, false>, d51, a, NW, LDS, LDS_MAX, MAX_GRID, st); break; \
     }
 
+// one-site tiles: the pair kernels
+#define DPTM_CONV_DISPATCH_PAIR(KERNEL, LDS, MAX_GRID)                                                            \
+    static bool p21[64] = {}, p33[64] = {}, p51[64] = {};                                                         \
+    switch (wlen) {                                                                                               \
+        case 21: e = launch_conv(&KERNEL<21>, p21, a, 4, LDS, LDS, MAX_GRID, st); break;                          \
+        case 33: e = launch_conv(&KERNEL<33>, p33, a, 4, LDS, LDS, MAX_GRID, st); break;                          \
+        default: e = launch_conv(&KERNEL<51>, p51, a, 4, LDS, LDS, MAX_GRID, st); break;                          \
+    }
+
 hipError_t t_conv_a_fwd(const ConvArgs& a, int wlen, int NW, hipStream_t st) {
     if (a.n_sites == 0) return hipSuccess;
     if (!tile_ok(wlen, a.S, NW, a.n_sites, a.ntiles)) return hipErrorInvalidValue;
     hipError_t e;
+    if (t_pair_tile(a.S, NW)) {
+        DPTM_CONV_DISPATCH_PAIR(conv_a_fwd_pair_kernel, conv_fwd_pair_lds(), 1024)
+        return e;
+    }
     DPTM_CONV_DISPATCH(conv_a_fwd_kernel, conv_fwd_lds(NW), conv_fwd_lds(8), 1024)
     return e;
 }
@@ -641,6 +1022,10 @@ hipError_t t_conv_b_fwd(const ConvArgs& a, int wlen, int NW, hipStream_t st) {
     if (a.n_sites == 0) return hipSuccess;
     if (!tile_ok(wlen, a.S, NW, a.n_sites, a.ntiles)) return hipErrorInvalidValue;
     hipError_t e;
+    if (t_pair_tile(a.S, NW)) {
+        DPTM_CONV_DISPATCH_PAIR(conv_b_fwd_pair_kernel, conv_fwd_pair_lds(), 1024)
+        return e;
+    }
     DPTM_CONV_DISPATCH(conv_b_fwd_kernel, conv_fwd_lds(NW), conv_fwd_lds(8), 1024)
     return e;
 }
@@ -683,7 +1068,11 @@ hipError_t t_conv_b_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW,
     if (a.n_sites == 0) return hipSuccess;
     if (!tile_ok(wlen, a.S, NW, a.n_sites, a.ntiles)) return hipErrorInvalidValue;
     hipError_t e;
-    DPTM_CONV_DISPATCH_BWD(conv_b_bwd_kernel, conv_bwd_lds(NW), conv_bwd_lds(8), kTbMaxParts)
+    if (t_pair_tile(a.S, NW)) {
+        DPTM_CONV_DISPATCH_PAIR(conv_b_bwd_pair_kernel, conv_bwd_pair_lds(), kTbMaxParts)
+    } else {
+        DPTM_CONV_DISPATCH_BWD(conv_b_bwd_kernel, conv_bwd_lds(NW), conv_bwd_lds(8), kTbMaxParts)
+    }
     if (e != hipSuccess) return e;
     if ((e = conv_b_bwd_plan(g, plan)) != hipSuccess) return e;
     PartUnits& ut = plan->units;
@@ -700,7 +1089,11 @@ hipError_t t_conv_a_bwd(const ConvArgs& a, const ConvGrads& g, int wlen, int NW,
     if (a.n_sites == 0) return hipSuccess;
     if (!tile_ok(wlen, a.S, NW, a.n_sites, a.ntiles)) return hipErrorInvalidValue;
     hipError_t e;
-    DPTM_CONV_DISPATCH_BWD(conv_a_bwd_kernel, conv_bwd_lds(NW), conv_bwd_lds(8), kTbMaxParts)
+    if (t_pair_tile(a.S, NW)) {
+        DPTM_CONV_DISPATCH_PAIR(conv_a_bwd_pair_kernel, conv_bwd_pair_lds(), kTbMaxParts)
+    } else {
+        DPTM_CONV_DISPATCH_BWD(conv_a_bwd_kernel, conv_bwd_lds(NW), conv_bwd_lds(8), kTbMaxParts)
+    }
     if (e != hipSuccess) return e;
     const int grid = (int)(a.ntiles < kTbMaxParts ? a.ntiles : kTbMaxParts);
     if ((e = conv_a_bwd_plan(g, wlen, plan)) != hipSuccess) return e;
@@ -733,28 +1126,36 @@ static hipError_t launch_conv3(K kernel, bool (&done)[64], const ConvArgs (&a)[3
     return hipGetLastError();
 }
 
+static bool pair3(const ConvArgs (&a)[3], int NW) {
+    return t_pair_tile(a[0].S, NW) && t_pair_tile(a[1].S, NW) && t_pair_tile(a[2].S, NW);
+}
+
 hipError_t t_conv_a_fwd3(const ConvArgs (&a)[3], int NW, hipStream_t st) {
-    static bool d4[64] = {}, d8[64] = {};
+    static bool d4[64] = {}, d8[64] = {}, dp[64] = {};
+    if (pair3(a, NW)) return launch_conv3(&conv_a_fwd3_pair_kernel, dp, a, NW, conv_fwd_pair_lds(), st);
     return NW == 4 ? launch_conv3(&conv_a_fwd3_kernel<256>, d4, a, NW, conv_fwd_lds(4), st)
                    : launch_conv3(&conv_a_fwd3_kernel<512>, d8, a, NW, conv_fwd_lds(8), st);
 }
 hipError_t t_conv_b_fwd3(const ConvArgs (&a)[3], int NW, hipStream_t st) {
-    static bool d4[64] = {}, d8[64] = {};
+    static bool d4[64] = {}, d8[64] = {}, dp[64] = {};
+    if (pair3(a, NW)) return launch_conv3(&conv_b_fwd3_pair_kernel, dp, a, NW, conv_fwd_pair_lds(), st);
     return NW == 4 ? launch_conv3(&conv_b_fwd3_kernel<256>, d4, a, NW, conv_fwd_lds(4), st)
                    : launch_conv3(&conv_b_fwd3_kernel<512>, d8, a, NW, conv_fwd_lds(8), st);
 }
 hipError_t t_conv_b_bwd3(const ConvArgs (&a)[3], const ConvGrads (&g)[3], int NW, PartPlan (&plan)[3], hipStream_t st) {
-    static bool d4[64] = {}, d8[64] = {};
-    hipError_t e = NW == 4 ? launch_conv3(&conv_b_bwd3_kernel<256>, d4, a, NW, conv_bwd_lds(4), st)
-                           : launch_conv3(&conv_b_bwd3_kernel<512>, d8, a, NW, conv_bwd_lds(8), st);
+    static bool d4[64] = {}, d8[64] = {}, dp[64] = {};
+    hipError_t e = pair3(a, NW) ? launch_conv3(&conv_b_bwd3_pair_kernel, dp, a, NW, conv_bwd_pair_lds(), st)
+                   : NW == 4    ? launch_conv3(&conv_b_bwd3_kernel<256>, d4, a, NW, conv_bwd_lds(4), st)
+                                : launch_conv3(&conv_b_bwd3_kernel<512>, d8, a, NW, conv_bwd_lds(8), st);
     for (int b = 0; b < 3 && e == hipSuccess; ++b) e = conv_b_bwd_plan(g[b], &plan[b]);
     return e;
 }
 // ... and, behind the last backward launch, ONE launch that adds the three branches' partial sums to the gradients
 hipError_t t_conv_a_bwd3(const ConvArgs (&a)[3], const ConvGrads (&g)[3], int NW, PartPlan (&plan)[3], hipStream_t st) {
-    static bool d4[64] = {}, d8[64] = {};
-    hipError_t e = NW == 4 ? launch_conv3(&conv_a_bwd3_kernel<256>, d4, a, NW, conv_bwd_lds(4), st)
-                           : launch_conv3(&conv_a_bwd3_kernel<512>, d8, a, NW, conv_bwd_lds(8), st);
+    static bool d4[64] = {}, d8[64] = {}, dp[64] = {};
+    hipError_t e = pair3(a, NW) ? launch_conv3(&conv_a_bwd3_pair_kernel, dp, a, NW, conv_bwd_pair_lds(), st)
+                   : NW == 4    ? launch_conv3(&conv_a_bwd3_kernel<256>, d4, a, NW, conv_bwd_lds(4), st)
+                                : launch_conv3(&conv_a_bwd3_kernel<512>, d8, a, NW, conv_bwd_lds(8), st);
     const int wl[3] = {21, 33, 51};
     for (int b = 0; b < 3 && e == hipSuccess; ++b) e = conv_a_bwd_plan(g[b], wl[b], &plan[b]);
     if (e != hipSuccess) return e;

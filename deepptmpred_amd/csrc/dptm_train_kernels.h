@@ -200,6 +200,8 @@ struct TbFwdArgs {
     float scale;           // 1 / (1 - rate)
 };
 hipError_t t_tb_fwd(const TbFwdArgs& a, int wlen, int NW, hipStream_t st);
+// a tile of ONE site in FOUR wavefronts runs the kernels of dptm_train_pair.h: two wavefronts share a 32-row block
+bool t_pair_tile(int S, int NW);
 
 // partial parameter gradients of one workgroup of the backward kernel (floats):
 //   24 weight-gradient units of 4096 (MFMA accumulator order) | 30 vectors of 64

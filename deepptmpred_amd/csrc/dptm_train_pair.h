@@ -1,5 +1,5 @@
-// "Pair" tiles of the fused TransformerBlock kernels (part of dptm_train_branch.hip, which includes this file behind its
-// own helpers): ONE site in FOUR wavefronts, for batches so small that a launch lasts as long as one wavefront's
+// "Pair" tiles of the fused training kernels (included by dptm_train_branch.hip behind its own helpers, and, for the
+// shared pieces, by dptm_train_conv.hip): ONE site in FOUR wavefronts, for batches so small that a launch lasts as long as one wavefront's
 // dependent chain (the reference trains with 64 sites per step, pred/train_PTM/config.py:56).  The site's rows fill two
 // 32-row blocks; wavefronts w and w + 2 both hold block w & 1 and share its work: every row product is cut in two --
 // by output tile (each wavefront 32 of the 64 output features), or by contraction half where the partial sums are
@@ -231,6 +231,21 @@ __device__ __forceinline__ void dw_unit_pair(const float* imgXT, const float* im
     for (int rg = 0; rg < 16; ++rg) dst[rg * 64] = acc[rg] + prev[rg];
     __syncthreads();
 }
+
+// sum over the wavefront's 32 rows of its own 32 features of a ROW-major image (own_rows: first row of its block)
+__device__ __forceinline__ float colsum_rows_own(const float* own_rows, int part, int lane) {
+    const int i = lane & 31, hh = lane >> 5;
+    const float* p = own_rows + 16 * hh * kLdsStride + 32 * part + i;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        s0 += p[r * kLdsStride];
+        s1 += p[(r + 1) * kLdsStride];
+    }
+    return xhalf_sum(s0 + s1);
+}
+
+#ifdef DPTM_PAIR_TB_BODIES      // the TransformerBlock bodies need the helpers of dptm_train_branch.hip
 
 // ------------------------------------------------------------------------------------ forward
 
@@ -770,3 +785,5 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
             pbuf[kTbUnits * 4096 + i] = vacc[i];
     }
 }
+
+#endif  // DPTM_PAIR_TB_BODIES
