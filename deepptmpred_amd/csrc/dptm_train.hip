@@ -163,6 +163,8 @@ struct dptm_trainer {
     // [esm 1280 f | struct 8 f | label i32 | codes 21 + 33 + 51]
     void* stage = nullptr;
     unsigned* d_step = nullptr;           // per-step scalars (StepParam)
+    int l2_slot = 0;                      // which of the two l2-value slots the step in hand uses
+    bool pooled_grad_in_kernel = false;   // this step's backward tiles form d(pooled rows) themselves (see TbBwdArgs::up_da)
     // captured graph of one forward_backward: replayed while the call's shape, buffers and options repeat
     struct GraphKey {
         int64_t n = -1;
@@ -510,6 +512,21 @@ TbBwdArgs tb_bwd_args(const Ctx& c, int b, const ConvArgs& cf, int64_t B, const 
     f.row_part = c.s->row_part;
     f.row_parts = (int)c.s->row_parts;
     f.queues = reinterpret_cast<unsigned*>(t->d_loss + 32) + 9 + b * 5;
+    // one-site tiles of a small batch take the gradient of their pooled rows from the first trunk layer themselves
+    f.up_da = nullptr;
+    f.up_w = nullptr;
+    f.up_n = f.up_cols = 0;
+    f.up_stream = f.up_thr = 0u;
+    f.up_scale = 1.0f;
+    if (t->pooled_grad_in_kernel && t_pair_tile(tc.S, tc.NW)) {
+        f.up_da = t->d512b;
+        f.up_w = c.w(t->pm.t1.k);
+        f.up_n = 512;
+        f.up_cols = kConcat;
+        f.up_stream = 24 + 2;
+        f.up_thr = dropout_threshold(rt.dense);
+        f.up_scale = rt.dense > 0.f ? 1.0f / (1.0f - rt.dense) : 1.0f;
+    }
     return f;
 }
 
@@ -539,7 +556,6 @@ int branch_bwd(const Ctx& c, int b, const uint8_t* tok, int64_t B, const unsigne
                int first = 0, int last = 2) {
     dptm_trainer* t = c.t;
     BranchAct& a = t->ba[b];
-    const BranchP& p = t->pm.br[b];
     const int wl = a.wlen;
     const TileCfg tc = t_tile_cfg(B, wl);
     const ConvArgs cf = conv_args(c, b, tok, B, seed, rt, tc);
@@ -721,6 +737,7 @@ int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spe
         hipMalloc((void**)&t->trainable, (size_t)t->pm.total) != hipSuccess ||
         hipMalloc((void**)&t->d_step, kStepParams * sizeof(unsigned)) != hipSuccess)
         return bail(DPTM_ENOMEM, "dptm_trainer_create: parameter buffers");
+    if (hipMemset(t->d_step, 0, kStepParams * sizeof(unsigned)) != hipSuccess) return bail(DPTM_EHIP, "dptm_trainer_create: step scalars");
     if (const char* env = std::getenv("DPTM_TRAIN_GRAPH")) t->use_graph = std::strcmp(env, "0") != 0;
     if (const char* env = std::getenv("DPTM_TRAIN_SERIAL")) t->serial = std::strcmp(env, "0") != 0;
     std::vector<float> host((size_t)t->pm.total, 0.0f);
@@ -910,7 +927,12 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
     // one launch: weight images of this step's weights; loss accumulator and BatchNorm column sums cleared; the gradient
     // buffer cleared, or set to the gradient of the l2 kernel regularisers (model.py:130-138,200,204), whose value
     // the head / loss kernel adds to the loss
-    T_TRY(t_pack(t->pack_jobs, t->n_pack_jobs, o->l2 > 0.f ? o->l2 * o->l2_scale : 0.f, t->d_step, st));
+    t->pooled_grad_in_kernel = false;
+    // (that launch also writes the step's scalars, unless the launches are being recorded for replay: see forward_backward_on)
+    const StepVals sv{o->seed, o->n_global > 0 ? (float)o->n_global : (float)n, (float)o->n_pos_global};
+    if (!t->use_graph) t->l2_slot ^= 1;
+    T_TRY(t_pack(t->pack_jobs, t->n_pack_jobs, o->l2 > 0.f ? o->l2 * o->l2_scale : 0.f, t->d_step, t->use_graph ? 0 : t->l2_slot,
+                 t->use_graph ? nullptr : &sv, st));
     // Small batches without a statistics all-reduce take the per-column kernels of dptm_train_site.hip: one launch per
     // layer and direction instead of a product and half a dozen element-wise passes each.
     const bool small = B <= kSiteMaxRows && !t->ar_fn &&
@@ -1080,10 +1102,17 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
         // head, loss and its gradient (trainer.py:36-54)
         T_TRY(t_head_loss(t->t2z, c.w(pm.head.k), c.w(pm.head.b), labels, B, t->d_step, t->proba, t->d_loss, t->d256a,
                           c.g(pm.head.k), c.g(pm.head.b), st));
+        // part (see SiteBwdArgs): with streams to spare the trunk's weight gradients leave the chain that leads to d(concat)
+        // and run on the per-site lane next to the branches' backward pass
+        // (not when the branches' workgroups fill the chip -- 78 to 85 sites in one-site tiles: 0.56 -> 0.58 ms with the cut)
+        int64_t branch_wgs = 0;
+        for (int b = 0; b < 3; ++b) branch_wgs += t_tile_cfg(B, kW[b]).ntiles;
+        const bool split_dw = ss != st && branch_wgs <= 232;
         auto bwd = [&](const float* dzd, const float* da_next, int Nn, const DenseP* next, int next_row_off, SiteDrop mid_drop,
                        float* gout, SiteDrop out_drop, const DenseP* L, bool bn, const float* mi, const float* a, float* da,
-                       const float* x, int64_t ldx, int K, SiteDrop in_drop, int N) {
+                       const float* x, int64_t ldx, int K, SiteDrop in_drop, int N, int part = 0) {
             SiteBwdArgs f;
+            f.part = part;
             f.dzd = dzd; f.ld_dzd = N;
             f.da_next = da_next; f.W_next = next ? c.w(next->k) : nullptr; f.Nn = Nn; f.next_row_off = next_row_off;
             f.mid_drop = mid_drop; f.gout = gout; f.ld_gout = kConcat; f.out_drop = out_drop;
@@ -1097,16 +1126,31 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
             f.N = N; f.B = (int)B; f.step = seed;
             return t_site_bwd(f, ls);
         };
-        T_TRY(bwd(t->d256a, nullptr, 0, nullptr, 0, none, nullptr, none, &pm.t2, true, t->t2mi, t->t2a, t->d256b, t->t1z, 512, 512, none, 256));
+        T_TRY(bwd(t->d256a, nullptr, 0, nullptr, 0, none, nullptr, none, &pm.t2, true, t->t2mi, t->t2a, t->d256b, t->t1z, 512, 512, none, 256,
+                  split_dw ? 1 : 0));
         T_TRY(bwd(nullptr, t->d256b, 256, &pm.t2, 0, none, nullptr, dropd(24 + 3, 512, 0), &pm.t1, true, t->t1mi, t->t1a, t->d512b,
-                  t->concat, kConcat, kConcat, dropd(24 + 2, kConcat, 0), 512));
-        // d(concat) of the three pooled branch outputs (columns 0..191), behind the concatenation's dropout
-        T_TRY(bwd(nullptr, t->d512b, 512, &pm.t1, 0, dropd(24 + 2, kConcat, 0), t->dconcat, none, nullptr, false, nullptr, nullptr, nullptr,
-                  nullptr, 0, 0, none, 192));
+                  t->concat, kConcat, kConcat, dropd(24 + 2, kConcat, 0), 512, split_dw ? 1 : 0));
+        // d(concat) of the three pooled branch outputs (columns 0..191), behind the concatenation's dropout -- unless every
+        // branch runs one-site tiles, which form their site's 64 values themselves: one launch less on the chain
+        t->pooled_grad_in_kernel = true;
+        for (int b = 0; b < 3; ++b) {
+            const TileCfg tcb = t_tile_cfg(B, kW[b]);
+            t->pooled_grad_in_kernel = t->pooled_grad_in_kernel && t_pair_tile(tcb.S, tcb.NW);
+        }
+        if (!t->pooled_grad_in_kernel)
+            T_TRY(bwd(nullptr, t->d512b, 512, &pm.t1, 0, dropd(24 + 2, kConcat, 0), t->dconcat, none, nullptr, false, nullptr, nullptr,
+                      nullptr, nullptr, 0, 0, none, 192));
         if ((rc = fork(1))) return rc;
         if ((rc = branches(false, 2, 2))) return rc;      // the longest lane first
         // ESM and structure layers on a stream of their own, side by side with the three branches
         ls = ss;
+        if (split_dw) {
+            // (ahead of the layers below, which overwrite d256a -- the head's gradient -- but not d256b / d512b)
+            T_TRY(bwd(t->d256a, nullptr, 0, nullptr, 0, none, nullptr, none, &pm.t2, true, t->t2mi, t->t2a, t->d256b, t->t1z, 512, 512, none,
+                      256, 2));
+            T_TRY(bwd(nullptr, t->d256b, 256, &pm.t2, 0, none, nullptr, dropd(24 + 3, 512, 0), &pm.t1, true, t->t1mi, t->t1a, t->d512b,
+                      t->concat, kConcat, kConcat, dropd(24 + 2, kConcat, 0), 512, 2));
+        }
         T_TRY(bwd(nullptr, t->d512b, 512, &pm.t1, 320, dropd(24 + 2, kConcat, 320), nullptr, none, &pm.esm2, false, nullptr, t->e2a, t->d256a,
                   t->e1, 512, 512, none, 256));
         T_TRY(bwd(nullptr, t->d512b, 512, &pm.t1, 192, dropd(24 + 2, kConcat, 192), nullptr, dropd(24 + 0, 128, 0), &pm.strct, true, t->smi,
@@ -1236,7 +1280,8 @@ static int forward_backward_on(dptm_trainer* t, const uint8_t* tok21, const uint
     const float ng = o->n_global > 0 ? (float)o->n_global : (float)n;
     t->n_local = n;
     t->n_global = o->n_global > 0 ? o->n_global : n;
-    T_TRY(t_set_step(t->d_step, o->seed, ng, (float)o->n_pos_global, st));
+    // a replayed graph cannot carry this call's scalars: a launch of its own writes them in front of it
+    if (t->use_graph) T_TRY(t_set_step(t->d_step, o->seed, ng, (float)o->n_pos_global, st));
     dptm_trainer::GraphKey key;
     key.n = n;
     const void* ptrs[6] = {tok21, tok33, tok51, strct, esm, labels};

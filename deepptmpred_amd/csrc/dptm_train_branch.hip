@@ -39,7 +39,19 @@ namespace dptm {
 // kind 1: dst[(h*(K/8) + u)*4 + e] = src[8u + 4h + e];  kind 2: dst[o] = src[o];  kind 3: dst[o] = 0 (o < K)
 // kind 4: l2 kernel regulariser (model.py:130-138,200,204) of K weights: dst[o] = 2*lambda*src[o] -- the gradient buffer
 //         starts from it, every later writer adds -- and lambda * sum src^2 joins step_params[kStepL2]
-__global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ jobs, float lambda, unsigned* __restrict__ step_params) {
+// The launch is the step's first: block (0, 0) also writes the step's scalars (set = 1), names the slot of the l2 value and
+// clears the other one for the next step.
+__global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ jobs, float lambda, unsigned* __restrict__ step_params,
+                                                   int l2_slot, int set, StepVals sv) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (set) {
+            step_params[kStepSeed] = sv.seed;
+            step_params[kStepNGlobal] = __float_as_uint(sv.n_global);
+            step_params[kStepNPosGlobal] = __float_as_uint(sv.n_pos_global);
+            step_params[kStepL2Sel] = (unsigned)l2_slot;
+            step_params[kStepL2 + (l2_slot ^ 1)] = 0u;
+        }
+    }
     const PackJob jb = jobs[blockIdx.y];
     if (jb.kind == 0) {
         const int total = jb.K * jb.N;
@@ -75,13 +87,16 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ j
         __syncthreads();
         if (threadIdx.x == 0) {
             const float t = (red[0] + red[1]) + (red[2] + red[3]);
-            if (t != 0.f) atomicAdd(reinterpret_cast<float*>(step_params) + kStepL2, lambda * t);
+            if (t != 0.f) atomicAdd(reinterpret_cast<float*>(step_params) + kStepL2 + l2_slot, lambda * t);
         }
     }
 }
 
-hipError_t t_pack(const PackJob* jobs_dev, int n_jobs, float lambda, unsigned* step_params, hipStream_t st) {
-    if (n_jobs) hipLaunchKernelGGL(pack_kernel, dim3(8, (unsigned)n_jobs), dim3(256), 0, st, jobs_dev, lambda, step_params);
+hipError_t t_pack(const PackJob* jobs_dev, int n_jobs, float lambda, unsigned* step_params, int l2_slot, const StepVals* sv,
+                  hipStream_t st) {
+    if (n_jobs < 1 || (l2_slot != 0 && l2_slot != 1)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_kernel, dim3(8, (unsigned)n_jobs), dim3(256), 0, st, jobs_dev, lambda, step_params, l2_slot, sv ? 1 : 0,
+                       sv ? *sv : StepVals{0u, 0.f, 0.f});
     return hipGetLastError();
 }
 

@@ -66,7 +66,11 @@ hipError_t t_copy_cols(float* dst, int64_t ldd, int dc, const float* src, int64_
 // Scalars that change every step live in a small device array so that a captured graph of the step can be
 // replayed unchanged: [kStepSeed] dropout seed, [kStepNGlobal] / [kStepNPosGlobal] float bits of the global
 // batch size and positive count of the loss weights.  t_set_step writes them (stream-ordered).
-enum StepParam { kStepSeed = 0, kStepNGlobal = 1, kStepNPosGlobal = 2, kStepL2 = 3, kStepParams = 4 };
+// [kStepL2 + s], s = [kStepL2Sel]: value of the l2 kernel regularisers of this step -- two slots taken in turn, so that
+// the launch that fills one can clear the other for the next step.
+enum StepParam { kStepSeed = 0, kStepNGlobal = 1, kStepNPosGlobal = 2, kStepL2 = 3, kStepL2Sel = 5, kStepParams = 6 };
+struct StepVals { unsigned seed; float n_global, n_pos_global; };
+// (a launch of its own: only where the step's launches are replayed from a graph; otherwise t_pack writes them)
 hipError_t t_set_step(unsigned* step_params, unsigned seed, float n_global, float n_pos_global, hipStream_t st);
 // x = dropout(src ? src : x); with rate 0 and a src this is a plain copy
 hipError_t t_dropout(float* x, int64_t rows, int cols, int64_t ld, int wlen_spatial, const unsigned* step_params, unsigned stream,
@@ -126,8 +130,10 @@ struct PackJob {
     float* dst;
     int kind, K, N, transpose;
 };
-// lambda: coefficient of the l2 kernel regularisers (kind 4 jobs); step_params[kStepL2] collects lambda * sum w^2
-hipError_t t_pack(const PackJob* jobs_dev, int n_jobs, float lambda, unsigned* step_params, hipStream_t st);
+// lambda: coefficient of the l2 kernel regularisers (kind 4 jobs); step_params[kStepL2 + l2_slot] collects lambda * sum w^2
+// and the other slot is cleared.  sv: the step's scalars, written by the same launch (NULL: t_set_step has written them).
+hipError_t t_pack(const PackJob* jobs_dev, int n_jobs, float lambda, unsigned* step_params, int l2_slot, const StepVals* sv,
+                  hipStream_t st);
 
 // transposed weight images of one TransformerBlock for the backward kernel, offsets in float4 units
 constexpr int kBtWqT = 0;                    // Wq^T, Wk^T, Wv^T, Wo^T: packed 64 x 64
@@ -246,6 +252,14 @@ struct TbBwdArgs {
     float* row_part;       // [2 blocks][row_parts][kRowPartStride] partial gradients of the row-wise launches (may be NULL)
     int row_parts;         // workgroups a row-wise launch may start (<= kRowMaxParts)
     unsigned* queues;      // five tile counters for the split form's launches, zero when the step starts
+    // One-site tiles may form the gradient of their pooled row themselves instead of reading dout (which then needs no
+    // launch of its own in front of this one): dout[f] = dropout(sum_n up_da[site][n] * up_w[(col_off + f) * up_n + n]),
+    // the layer above being a dense layer of up_n units whose input dropout (element index site * up_cols + column) is
+    // up_stream / up_thr / up_scale.  up_da == nullptr: read dout.
+    const float *up_da, *up_w;
+    int up_n, up_cols;
+    unsigned up_stream, up_thr;
+    float up_scale;
 };
 // Row-wise half of one TransformerBlock's backward pass (no site structure: tiles of any 128 rows).
 constexpr int kRowUnits = 8;       // dW1 chunks 0..3, dW2 chunks 0..3
@@ -410,6 +424,9 @@ struct SiteBwdArgs {
     float l2c;               // dW = x^T d(a) + l2c * W (l2c = 0: no regulariser, W is not read)
     int N, B;
     const unsigned* step;
+    // 0: the whole layer.  The weight gradient is needed by nobody on the way down, so a step may cut the launch in two:
+    // 1 = everything but dW (d(a), bias / BatchNorm gradients), 2 = dW alone from the d(a) that launch left, on any stream
+    int part;
 };
 hipError_t t_site_bwd(const SiteBwdArgs& a, hipStream_t st);
 

@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const float* __restrict_
     }
     if (threadIdx.x < 3) {
         float v = red_s[0][threadIdx.x] + red_s[1][threadIdx.x] + red_s[2][threadIdx.x] + red_s[3][threadIdx.x];
-        if (threadIdx.x == 0 && blockIdx.x == 0) v += __uint_as_float(step_params[kStepL2]);   // l2 regularisers (pack_kernel)
+        if (threadIdx.x == 0 && blockIdx.x == 0) v += __uint_as_float(step_params[kStepL2 + (step_params[kStepL2Sel] & 1u)]);   // l2 regularisers (pack_kernel)
         atomicAdd(threadIdx.x == 0 ? loss : db + threadIdx.x - 1, v);
     }
 }
@@ -1353,6 +1353,7 @@ __global__ void set_step_kernel(unsigned* step_params, unsigned seed, float n_gl
         step_params[kStepNGlobal] = __float_as_uint(n_global);
         step_params[kStepNPosGlobal] = __float_as_uint(n_pos_global);
         step_params[kStepL2] = 0u;       // the step's first launch adds the l2 regularisers' value here
+        step_params[kStepL2Sel] = 0u;
     }
 }
 hipError_t t_set_step(unsigned* step_params, unsigned seed, float n_global, float n_pos_global, hipStream_t st) {

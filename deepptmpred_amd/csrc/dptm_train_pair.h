@@ -247,6 +247,16 @@ __device__ __forceinline__ float colsum_rows_own(const float* own_rows, int part
 
 #ifdef DPTM_PAIR_TB_BODIES      // the TransformerBlock bodies need the helpers of dptm_train_branch.hip
 
+// What a small batch keeps for its backward pass fits the caches (64 sites: 15 MB over eight 4 MB L2s and the infinity
+// cache behind them), and a workgroup meets its own rows again: plain stores and loads here, not the streaming ones.
+#ifdef DPTM_EXP_PAIR_NT
+__device__ __forceinline__ void pkeep_store(f32x4* p, const f32x4& v) { keep_store(p, v); }
+__device__ __forceinline__ f32x4 pkeep_load(const f32x4* p) { return keep_load(p); }
+#else
+__device__ __forceinline__ void pkeep_store(f32x4* p, const f32x4& v) { *p = v; }
+__device__ __forceinline__ f32x4 pkeep_load(const f32x4* p) { return *p; }
+#endif
+
 // ------------------------------------------------------------------------------------ forward
 
 // LDS: K rows | V rows | exchange buffers | pooling scores, weights | BatchNorm 2 scale, shift
@@ -297,13 +307,13 @@ __device__ __forceinline__ void tb_fwd_pair_body(const TbFwdArgs& p) {
                 gemm_regs<8, 1>(acc, Th + kTbWk, x1, lane);
                 acc_to_x<1>(acc, t);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) keep_store(&sv.k[co + g * 64], t[g]);
+                for (int g = 0; g < 4; ++g) pkeep_store(&sv.k[co + g * 64], t[g]);
                 chain_store4(mine_a, h, part, t);
                 acc_init_bias<1>(acc, tvh + kVBv * kVec64, h, 8);
                 gemm_regs<8, 1>(acc, Th + kTbWv, x1, lane);
                 acc_to_x<1>(acc, t);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) keep_store(&sv.v[co + g * 64], t[g]);
+                for (int g = 0; g < 4; ++g) pkeep_store(&sv.v[co + g * 64], t[g]);
                 chain_store4(mine_b, h, part, t);
             }
             float q1[1][16];
@@ -314,7 +324,7 @@ __device__ __forceinline__ void tb_fwd_pair_body(const TbFwdArgs& p) {
                 gemm_regs<8, 1>(acc, Th + kTbWq, x1, lane);
                 acc_to_x<1>(acc, t);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) keep_store(&sv.q[co + g * 64], t[g]);
+                for (int g = 0; g < 4; ++g) pkeep_store(&sv.q[co + g * 64], t[g]);
                 x4_to_head(t, q1[0], kQScale);
             }
             __syncthreads();   // K and V of the site are in LDS
@@ -326,7 +336,7 @@ __device__ __forceinline__ void tb_fwd_pair_body(const TbFwdArgs& p) {
                 f32x4 o4[4];
                 head_to_x4(o1[0], o4, 1.0f);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) keep_store(&sv.o[co + g * 64], o4[g]);
+                for (int g = 0; g < 4; ++g) pkeep_store(&sv.o[co + g * 64], o4[g]);
                 pair_gather(px, wave, lane, part, o4, o);
             }
             // output projection, dropout, residual, LayerNorm 1
@@ -347,7 +357,7 @@ __device__ __forceinline__ void tb_fwd_pair_body(const TbFwdArgs& p) {
                 iv[0] = ln_normalise(t);
                 own_groups(t, part, t4);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) keep_store(&sv.xh1[co + g * 64], t4[g]);
+                for (int g = 0; g < 4; ++g) pkeep_store(&sv.xh1[co + g * 64], t4[g]);
                 ln_affine(t, tv + kVLn1G * kVec64, tv + kVLn1B * kVec64, h, hres);
             }
             // FFN: this wavefront's two of the four hidden chunks; the partial sums meet
@@ -381,7 +391,7 @@ __device__ __forceinline__ void tb_fwd_pair_body(const TbFwdArgs& p) {
                 f32x4 t4[4];
                 own_groups(t, part, t4);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) keep_store(&sv.xh2[co + g * 64], t4[g]);
+                for (int g = 0; g < 4; ++g) pkeep_store(&sv.xh2[co + g * 64], t4[g]);
                 ln_affine(t, tv + kVLn2G * kVec64, tv + kVLn2B * kVec64, h, x1);
             }
             if (part == 0) sv.inv[cl] = iv;
@@ -456,6 +466,7 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
     __syncthreads();
     bool first = true;
     int tile_round = 0;
+    PH_DECL
 #pragma unroll 1
     for (int64_t tile = next_tile(p.queue, tile_slot, tile_round); tile < p.ntiles; tile = next_tile(p.queue, tile_slot, tile_round)) {
         const int64_t grow = tile * W + row;
@@ -474,10 +485,30 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
             const f32x4* pv = p.P + kOffPoolV;
             f32x4 x[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = keep_load(&AT4(p.sv[1].xh2, u));
+            for (int u = 0; u < 8; ++u) x[u] = pkeep_load(&AT4(p.sv[1].xh2, u));
             ln_affine(x, tv1 + kVLn2G * kVec64, tv1 + kVLn2B * kVec64, h, x);
             const f32x2 pa = AT1(p.pool);
             const float* dsite = p.dout + tile * p.ldd + p.col_off;
+            if (p.up_da) {
+                // the site's 64 pooled-row gradients from the layer above: four threads per feature, a quarter of the sum each
+                float* dsl = xreg + kPairXreg - 64;
+                const int f = tid >> 2, q = tid & 3, quarter = p.up_n >> 2;
+                const f32x4* wr = reinterpret_cast<const f32x4*>(p.up_w + (int64_t)(p.col_off + f) * p.up_n + quarter * q);
+                const f32x4* dr = reinterpret_cast<const f32x4*>(p.up_da + tile * p.up_n + quarter * q);
+                f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 16
+                for (int i = 0; i < (quarter >> 2); ++i) a4 += wr[i] * dr[i];
+                float acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+                acc += __shfl_xor(acc, 1);
+                acc += __shfl_xor(acc, 2);
+                if (p.up_thr) {
+                    const unsigned idx = (unsigned)(tile * p.up_cols) + (unsigned)(p.col_off + f);
+                    acc = hash_u32(seed, p.up_stream, idx) >= p.up_thr ? acc * p.up_scale : 0.f;
+                }
+                if (q == 0) dsl[f] = acc;
+                __syncthreads();
+                dsite = dsl;
+            }
             f32x4 ds[8];
             float dal = 0.f;
 #pragma unroll
@@ -514,6 +545,7 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
             wave_fence();
             __syncthreads();   // the scores in xreg have been read
         }
+        PH_MARK(0)   // pooling backward
 #pragma unroll 1
         for (int blk = 1; blk >= 0; --blk) {
             const f32x4* T = p.P + kOffTb + blk * kTbSize;
@@ -528,13 +560,14 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
             {
                 f32x4 xh[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) xh[u] = keep_load(&AT4(sv.xh2, u));
+                for (int u = 0; u < 8; ++u) xh[u] = pkeep_load(&AT4(sv.xh2, u));
                 ln_backward_pair(dy, xh, iv[1], tv + kVLn2G * kVec64, h, part, dsum, lane_a, lane_b);
                 wave_fence();
                 colsum_own(bufA, row0, part, lane, va + kSG2 * 64);
                 colsum_own(bufB, row0, part, lane, va + kSB2 * 64);
                 wave_fence();
             }
+            PH_MARK(1)   // LayerNorm 2 backward
             f32x4 df2[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) df2[u] = dsum[u];
@@ -543,7 +576,7 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
             {
                 f32x4 xh[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) xh[u] = keep_load(&AT4(sv.xh1, u));
+                for (int u = 0; u < 8; ++u) xh[u] = pkeep_load(&AT4(sv.xh1, u));
                 ln_affine(xh, tv + kVLn1G * kVec64, tv + kVLn1B * kVec64, h, hx);
             }
             // ---- feed-forward layers backward.  Every hidden chunk is cut by output tile: this wavefront rebuilds 32 of the
@@ -590,29 +623,36 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
                     wave_fence();
                     colsum_own(bufB, row0, part, lane, va + kSFb2 * 64);
                 }
+                PH_MARK(2)   // feed-forward row products
                 __syncthreads();
                 dw_unit_pair(bufA, bufB, pu + (4 + c) * 4096, first, lane, wave, W);     // dW2[chunk, :] += u_c^T d(f2)
+                PH_MARK(3)   // feed-forward weight gradients
                 chain_store_t4(lane_a, part, hxo);
                 chain_store_t4(lane_b, part, d1);
                 wave_fence();
                 colsum_own(bufB, row0, part, lane, va + (kSFb1 + c) * 64);
                 gemm_groups4<32>(acc_dh, TT + kBtW1T, 8 * c + 4 * part, d1, lane);      // d(h) += d(f1_c) W1[:, my units]^T
+                PH_MARK(2)
                 __syncthreads();
                 dw_unit_pair(bufA, bufB, pu + c * 4096, first, lane, wave, W);           // dW1[:, chunk] += h^T d(f1_c)
+                PH_MARK(3)
             }
             // ---- LayerNorm 1 backward: d(h) -> dsum = d(x + ao)
             {
                 f32x4 dh[8], xh[8];
                 acc_to_x<2>(acc_dh, dh);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) xh[u] = keep_load(&AT4(sv.xh1, u));
+                for (int u = 0; u < 8; ++u) xh[u] = pkeep_load(&AT4(sv.xh1, u));
+                PH_MARK(2)
                 pair_sum(px, wave, lane, dh);
+                PH_MARK(9)   // exchanges between the two wavefronts of a pair
                 ln_backward_pair(dh, xh, iv[0], tv + kVLn1G * kVec64, h, part, dsum, lane_a, lane_b);
                 wave_fence();
                 colsum_own(bufA, row0, part, lane, va + kSG1 * 64);
                 colsum_own(bufB, row0, part, lane, va + kSB1 * 64);
                 wave_fence();
             }
+            PH_MARK(4)   // LayerNorm 1 backward
             // ---- output projection backward: this wavefront's output tile of d(o) holds exactly its two heads
             f32x4 dO[4];
             float D;           // D = dO . o of the lane's head (= sum_t p_t dO.v_t)
@@ -621,7 +661,7 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) dao[u] = dsum[u];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) o4[g] = keep_load(&AT4O(sv.o, g));
+                for (int g = 0; g < 4; ++g) o4[g] = pkeep_load(&AT4O(sv.o, g));
                 dropout_chain(dao, grow, h, seed, p.stream_base + 2 * blk, p.thr, p.scale);
                 own_groups(dao, part, dao4);
                 chain_store_t4(lane_a, part, o4);
@@ -644,6 +684,7 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
                 s23 = xhalf_sum(s23);
                 D = h ? s23 : s01;
             }
+            PH_MARK(5)   // output projection backward
             const f32x4 st = ((sv.stat) + tww * 64)[local_index(ln)];
             f32x16 acc_dx[2];   // d(x) = dsum + dq Wq^T + dk Wk^T + dv Wv^T: partial sums over this wavefront's groups
             if (part == 0)
@@ -656,21 +697,23 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
                 {
                     f32x4 t[4];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) t[g] = keep_load(&AT4O(sv.k, g));
+                    for (int g = 0; g < 4; ++g) t[g] = pkeep_load(&AT4O(sv.k, g));
                     chain_store4(mine_a, h, part, t);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) t[g] = keep_load(&AT4O(sv.v, g));
+                    for (int g = 0; g < 4; ++g) t[g] = pkeep_load(&AT4O(sv.v, g));
                     chain_store4(mine_b, h, part, t);
                     float qs[16], doh[16], gh[16];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) t[g] = keep_load(&AT4O(sv.q, g));
+                    for (int g = 0; g < 4; ++g) t[g] = pkeep_load(&AT4O(sv.q, g));
                     x4_to_head(t, qs, kQScale);
                     x4_to_head(dO, doh, 1.0f);
                     __syncthreads();   // K and V of the site are in LDS
                     attn_bwd_q<W>(bufA + head_off, bufB + head_off, qs, doh, st[0], st[1], D, gh);
                     head_to_x4(gh, dq, row_ok ? 0.25f : 0.f);
                 }
+                PH_MARK(6)   // attention backward, query rows
                 __syncthreads();   // K and V have been read
+                PH_MARK(10)  // barrier after a vector-unit phase
                 {
                     f32x4 xin[4];
                     if (blk == 0) {
@@ -679,7 +722,7 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
                         const f32x4* tv0 = p.P + kOffTb + kTbVec;
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
-                            xin[g] = keep_load(&AT4O(p.sv[0].xh2, g)) * tv0[kVLn2G * kVec64 + h * 8 + 4 * part + g] +
+                            xin[g] = pkeep_load(&AT4O(p.sv[0].xh2, g)) * tv0[kVLn2G * kVec64 + h * 8 + 4 * part + g] +
                                      tv0[kVLn2B * kVec64 + h * 8 + 4 * part + g];
                     }
                     chain_store_t4(lane_a, part, xin);
@@ -691,13 +734,14 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
                 dw_unit_pair(bufA, bufB, pu + 9 * 4096, first, lane, wave, W);           // dWq += x^T dq
                 gemm_groups4<8>(acc_dx, TT + kBtWqT, 4 * part, dq, lane);
             }
+            PH_MARK(7)   // Q / K / V projections backward
             // ---- attention backward, lane = key row: dk, dv
             {
                 f32x4 dk[4], dv[4];
                 {
                     f32x4 t[4];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) t[g] = keep_load(&AT4O(sv.q, g)) * kQScale;
+                    for (int g = 0; g < 4; ++g) t[g] = pkeep_load(&AT4O(sv.q, g)) * kQScale;
                     chain_store4(mine_a, h, part, t);
                     chain_store4(mine_b, h, part, dO);
                     xreg[64 + row * 4 + 2 * part + h] = st[0];
@@ -705,17 +749,19 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
                     xreg[64 + 512 + row * 4 + 2 * part + h] = D;
                     float kh[16], vh[16], gk[16], gv[16];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) t[g] = keep_load(&AT4O(sv.k, g));
+                    for (int g = 0; g < 4; ++g) t[g] = pkeep_load(&AT4O(sv.k, g));
                     x4_to_head(t, kh, 1.0f);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) t[g] = keep_load(&AT4O(sv.v, g));
+                    for (int g = 0; g < 4; ++g) t[g] = pkeep_load(&AT4O(sv.v, g));
                     x4_to_head(t, vh, 1.0f);
                     __syncthreads();   // scaled Q, dO and the statistics of the site are in LDS
                     attn_bwd_kv<W>(bufA + head_off, bufB + head_off, xreg + 64 + 2 * part + h, 256, kh, vh, gk, gv);
                     head_to_x4(gk, dk, row_ok ? kLn2 : 0.f);
                     head_to_x4(gv, dv, row_ok ? 1.0f : 0.f);
                 }
+                PH_MARK(8)   // attention backward, key rows
                 __syncthreads();   // Q and dO have been read
+                PH_MARK(10)
                 {
                     f32x4 xin[4];
                     if (blk == 0) {
@@ -724,7 +770,7 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
                         const f32x4* tv0 = p.P + kOffTb + kTbVec;
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
-                            xin[g] = keep_load(&AT4O(p.sv[0].xh2, g)) * tv0[kVLn2G * kVec64 + h * 8 + 4 * part + g] +
+                            xin[g] = pkeep_load(&AT4O(p.sv[0].xh2, g)) * tv0[kVLn2G * kVec64 + h * 8 + 4 * part + g] +
                                      tv0[kVLn2B * kVec64 + h * 8 + 4 * part + g];
                     }
                     chain_store_t4(lane_a, part, xin);
@@ -743,7 +789,9 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
                 gemm_groups4<8>(acc_dx, TT + kBtWvT, 4 * part, dv, lane);
             }
             acc_to_x<2>(acc_dx, dy);
+            PH_MARK(7)
             pair_sum(px, wave, lane, dy);
+            PH_MARK(9)
         }
         // d(x1) leaves chain-tiled; its column sums (with swish(a2)) feed the second BatchNorm's backward pass
         {
@@ -784,6 +832,7 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
         else
             pbuf[kTbUnits * 4096 + i] = vacc[i];
     }
+    PH_FLUSH
 }
 
 #endif  // DPTM_PAIR_TB_BODIES

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(512) void site_bwd_kernel(SiteBwdArgs p) {
     // per-column parameters of this thread's column (c = tid & 31 in every loop below): requested before the product
     const int cc = tid & 31;
     const float mu_c = p.bn ? p.mi[n0 + cc] : 0.f, inv_c = p.bn ? p.mi[p.N + n0 + cc] : 1.f, gamma_c = p.bn ? p.gamma[n0 + cc] : 1.f;
+    if (p.part != 2) {
     if (p.a) {
         for (int o = tid; o < p.B * 32; o += 512) {
             const int r = o >> 5, c = o & 31;
@@ -306,6 +307,19 @@ __global__ __launch_bounds__(512) void site_bwd_kernel(SiteBwdArgs p) {
             v2 = 0.f;
         }, red, db1, cs2);
         if (tid < 32) p.db[n0 + tid] += db1[tid];
+    }
+    if (p.part == 1) {     // the weight gradient follows in a launch of its own
+        PH_MARK(10)
+        PH_FLUSH
+        return;
+    }
+    } else {
+        // d(a) of my columns, as the first launch left it; rows behind the batch hold zeros
+        for (int o = tid; o < RT * 32 * 32; o += 512) {
+            const int r = o >> 5, c = o & 31;
+            tile[r * kTilePad + c] = r < p.B ? p.da[(int64_t)r * p.N + n0 + c] : 0.f;
+        }
+        __syncthreads();
     }
     // ---- my 32 columns of dW = x^T d(a): 32-row blocks of dW over the wavefronts, contraction over the batch rows
     // (rows 8q + 4hh + e meet in step 4q + e; all loads of a block are requested before its first product)
@@ -387,7 +401,8 @@ hipError_t t_site_fwd(const SiteFwdArgs& a, hipStream_t st) {
 }
 
 hipError_t t_site_bwd(const SiteBwdArgs& a, hipStream_t st) {
-    if (a.B < 1 || a.B > kSiteMaxRows || a.N % 32 != 0 || (!a.dzd && a.Nn % 8 != 0)) return hipErrorInvalidValue;
+    if (a.B < 1 || a.B > kSiteMaxRows || a.N % 32 != 0 || (a.part != 2 && !a.dzd && a.Nn % 8 != 0)) return hipErrorInvalidValue;
+    if (a.part < 0 || a.part > 2 || (a.part != 0 && (!a.a || !a.da || !a.dW))) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(a.N / 32)), block(512);
     const int rt = (a.B + 31) / 32;
     if (rt == 1)

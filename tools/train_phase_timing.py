@@ -6,7 +6,7 @@ import numpy as np
 import torch
 from deepptmpred_amd import spec, _native
 names = ["pool bwd", "LN2 bwd", "FFN row products", "FFN dW units", "LN1 bwd", "Wo bwd (dW + dO)", "attn bwd q-pass",
-         "QKV bwd (dW + dx)", "attn bwd k-pass", "-", "barrier after attn", "-"]
+         "QKV bwd (dW + dx)", "attn bwd k-pass", "pair exchanges", "barrier after attn", "-"]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 lib = _native.load_library()
 w = spec.synthetic_weights(7)
