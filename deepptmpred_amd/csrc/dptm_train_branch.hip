@@ -72,13 +72,37 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackJob* __restrict__ j
     } else if (jb.kind == 2) {
         for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < jb.K; o += gridDim.x * blockDim.x) jb.dst[o] = jb.src[o];
     } else if (jb.kind == 3) {
-        for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < jb.K; o += gridDim.x * blockDim.x) jb.dst[o] = 0.f;
+        // (spans start and end on multiples of four floats wherever the tables allow: vector stores, scalar tail)
+        const bool vec = ((reinterpret_cast<uintptr_t>(jb.dst) & 15) == 0);
+        const int k4 = vec ? jb.K >> 2 : 0;
+        f32x4* d4 = reinterpret_cast<f32x4*>(jb.dst);
+        for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < k4; o += gridDim.x * blockDim.x) d4[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int o = 4 * k4 + blockIdx.x * blockDim.x + threadIdx.x; o < jb.K; o += gridDim.x * blockDim.x) jb.dst[o] = 0.f;
     } else {
         __shared__ float red[4];
         float s = 0.f;
-        for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < jb.K; o += gridDim.x * blockDim.x) {
-            const float v = jb.src[o];
-            jb.dst[o] = 2.0f * lambda * v;
+        const bool vec = ((reinterpret_cast<uintptr_t>(jb.dst) | reinterpret_cast<uintptr_t>(jb.src)) & 15) == 0;
+        const int k4 = vec ? jb.K >> 2 : 0;
+        const f32x4* s4 = reinterpret_cast<const f32x4*>(jb.src);
+        f32x4* d4 = reinterpret_cast<f32x4*>(jb.dst);
+        const int stride4 = gridDim.x * blockDim.x;
+        int o = blockIdx.x * blockDim.x + threadIdx.x;
+        for (; o + stride4 < k4; o += 2 * stride4) {       // two loads in flight
+            const f32x4 v = s4[o], w = s4[o + stride4];
+            d4[o] = (2.0f * lambda) * v;
+            d4[o + stride4] = (2.0f * lambda) * w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = fmaf(v[e], v[e], fmaf(w[e], w[e], s));
+        }
+        if (o < k4) {
+            const f32x4 v = s4[o];
+            d4[o] = (2.0f * lambda) * v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = fmaf(v[e], v[e], s);
+        }
+        for (int o1 = 4 * k4 + blockIdx.x * blockDim.x + threadIdx.x; o1 < jb.K; o1 += gridDim.x * blockDim.x) {
+            const float v = jb.src[o1];
+            jb.dst[o1] = 2.0f * lambda * v;
             s = fmaf(v, v, s);
         }
 #pragma unroll
@@ -1097,15 +1121,17 @@ __device__ __forceinline__ void reduce_parts_body(const float* __restrict__ part
         src = part + vt.off[v] + f;
         dst = vt.dst[v] + f;
     }
-    float a0 = 0.f, a1 = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;      // four loads in flight: the launch is bound by their latency
     int pi = blockIdx.y;
     const int stepp = gridDim.y;
-    for (; pi + stepp < nparts; pi += 2 * stepp) {
+    for (; pi + 3 * stepp < nparts; pi += 4 * stepp) {
         a0 += src[(size_t)pi * stride];
         a1 += src[(size_t)(pi + stepp) * stride];
+        a2 += src[(size_t)(pi + 2 * stepp) * stride];
+        a3 += src[(size_t)(pi + 3 * stepp) * stride];
     }
-    if (pi < nparts) a0 += src[(size_t)pi * stride];
-    atomicAdd(dst, a0 + a1);
+    for (; pi < nparts; pi += stepp) a0 += src[(size_t)pi * stride];
+    atomicAdd(dst, (a0 + a1) + (a2 + a3));
 }
 
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, int nparts, PartUnits ut, PartVecs vt,
