@@ -132,7 +132,7 @@ if os.path.exists(tb) and bench_line("trace_bench.json"):
 
 # ---------------------------------------------------------------- training step
 # The backward pass of the W=51 branch's TransformerBlocks + pooling is ONE launch at small batches
-# (tb_bwd_kernel<51, 256, 0>) and FIVE at large ones: tb_bwd_kernel<51, 512, 1> (pooling), then per block
+# (tb_bwd_pair_kernel<51> up to 85 sites, tb_bwd_kernel<51, 256, 0> above) and FIVE at large ones: tb_bwd_kernel<51, 512, 1> (pooling), then per block
 # tb_row_bwd_kernel (row-wise half; one kernel for all window sizes -- the W=51 launches are the longest third of its
 # launches) and tb_bwd_kernel<51, 512, 2> (attention half).  Counters and durations are summed over those launches:
 # "per launch" below means per backward pass of the branch.
@@ -143,13 +143,13 @@ def bwd51(agg):
     """(label, {counter: [per-pass value]}, launches per pass) of the W=51 backward pass"""
     parts = []
     for k, v in agg.items():
-        if "tb_bwd_kernel<51" in k:
+        if "tb_bwd_kernel<51" in k or "tb_bwd_pair_kernel<51" in k:
             parts.append((k, v, None))
         elif "tb_row_bwd_kernel" in k:
             parts.append((k, v, "top_third"))
     if not parts:
         return None, None, 0
-    passes = min(len(v["_dur_ns"]) for k, v, sel in parts if sel is None and (k.endswith(", 1>") or k.endswith(", 0>")))
+    passes = min(len(v["_dur_ns"]) for k, v, sel in parts if sel is None and (k.endswith(", 1>") or k.endswith(", 0>") or "pair" in k))
     out = collections.defaultdict(float)
     launches = 0
     for k, v, sel in parts:
