@@ -447,3 +447,50 @@ def test_gradients_of_a_repeated_batch_equal_those_of_one_period():
         print("copies", k, "max gradient difference / largest gradient %.2e" % err)
         assert err < 2e-4, (k, err)
     tr.close()
+
+
+_TILE_FORM_SCRIPT = """
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, {root!r})
+from deepptmpred_amd import _native, spec
+n = {n}
+w = spec.synthetic_weights(3)
+x = spec.synthetic_inputs(n, 11)
+y = (np.random.default_rng(2).random(n) < 0.3).astype(np.int64)
+dev = torch.device("cuda:0")
+d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in x]
+lab = torch.from_numpy(y.astype(np.int32)).to(dev)
+tr = _native.Trainer(spec.pack_blob(w), max_batch=64)
+o = _native.TrainOpts()
+o.seed = 5
+o.rate_embed, o.rate_conv, o.rate_tb, o.rate_dense = 1e-4, 0.3, 0.1, 0.3
+o.n_global = n; o.n_pos_global = int(y.sum()); o.l2 = 1e-4; o.l2_scale = 1.0
+loss = tr.forward_backward(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), lab.data_ptr(), n, o)
+torch.cuda.synchronize()
+np.save({out!r}, np.concatenate([tr.get_grads(), np.float32([loss])]))
+"""
+
+
+def test_one_site_tiles_with_and_without_shared_row_blocks_agree(tmp_path):
+    """Batches of up to 85 sites run one site per workgroup with TWO wavefronts per 32-row block (row products cut by
+    output tile or contraction half, a head per lane).  A second process with that form switched off
+    (DPTM_TRAIN_PAIR=0: one wavefront per row block, the other two only share the weight-gradient units) must leave
+    the same loss and gradients -- dropout on, so the masks of both forms are the same masks."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for form in ("1", "0"):
+        out = str(tmp_path / f"grads_pair{form}.npy")
+        env = dict(os.environ, DPTM_TRAIN_PAIR=form)
+        r = subprocess.run([sys.executable, "-c", _TILE_FORM_SCRIPT.format(root=root, n=40, out=out)], env=env, capture_output=True,
+                           text=True, timeout=240)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[form] = np.load(out)
+    a, b = got["1"], got["0"]
+    assert a.shape == b.shape and np.isfinite(a).all()
+    assert abs(a[-1] - b[-1]) < 1e-6 * max(1.0, abs(b[-1]))                      # loss
+    assert np.abs(a[:-1] - b[:-1]).max() < 1e-5 * np.abs(b[:-1]).max()           # every gradient, flat
