@@ -232,6 +232,54 @@ __device__ __forceinline__ void dw_unit_pair(const float* imgXT, const float* im
     __syncthreads();
 }
 
+// Two units behind ONE barrier (both pairs of images complete before the call): the two chains of matrix instructions
+// interleave, and the second unit's LDS reads and partial-buffer traffic hide behind the first's products.
+__device__ __forceinline__ void dw_unit_pair2(const float* x1, const float* y1, float* __restrict__ part1, const float* x2,
+                                              const float* y2, float* __restrict__ part2, bool first, int lane, int wave,
+                                              int rows_valid) {
+    const int hh = lane >> 5, i = lane & 31;
+    const int b = wave;
+    const int ox = (32 * (b >> 1) + i) * kLdsStride + 4 * hh, oy = (32 * (b & 1) + i) * kLdsStride + 4 * hh;
+    const float *ap1 = x1 + ox, *bp1 = y1 + oy, *ap2 = x2 + ox, *bp2 = y2 + oy;
+    float* dst1 = part1 + b * 1024 + lane;
+    float* dst2 = part2 + b * 1024 + lane;
+    f32x16 acc1, acc2, prev1, prev2;
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) acc1[rg] = acc2[rg] = prev1[rg] = prev2[rg] = 0.f;
+    if (!first) {
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+            prev1[rg] = dst1[rg * 64];
+            prev2[rg] = dst2[rg * 64];
+        }
+    }
+    const int nq = (rows_valid + 7) >> 3;
+    f32x4 ca1 = *reinterpret_cast<const f32x4*>(ap1), cb1 = *reinterpret_cast<const f32x4*>(bp1);
+    f32x4 ca2 = *reinterpret_cast<const f32x4*>(ap2), cb2 = *reinterpret_cast<const f32x4*>(bp2);
+#pragma unroll 2
+    for (int g = 0; g < nq; ++g) {
+        f32x4 na1 = ca1, nb1 = cb1, na2 = ca2, nb2 = cb2;
+        if (g + 1 < nq) {
+            na1 = *reinterpret_cast<const f32x4*>(ap1 + 8 * (g + 1));
+            nb1 = *reinterpret_cast<const f32x4*>(bp1 + 8 * (g + 1));
+            na2 = *reinterpret_cast<const f32x4*>(ap2 + 8 * (g + 1));
+            nb2 = *reinterpret_cast<const f32x4*>(bp2 + 8 * (g + 1));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mfma(acc1, ca1[e], cb1[e]);
+            mfma(acc2, ca2[e], cb2[e]);
+        }
+        ca1 = na1; cb1 = nb1; ca2 = na2; cb2 = nb2;
+    }
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+        dst1[rg * 64] = acc1[rg] + prev1[rg];
+        dst2[rg * 64] = acc2[rg] + prev2[rg];
+    }
+    __syncthreads();
+}
+
 // sum over the wavefront's 32 rows of its own 32 features of a ROW-major image (own_rows: first row of its block)
 __device__ __forceinline__ float colsum_rows_own(const float* own_rows, int part, int lane) {
     const int i = lane & 31, hh = lane >> 5;
@@ -434,9 +482,11 @@ __device__ __forceinline__ void tb_fwd_pair_body(const TbFwdArgs& p) {
 
 // ------------------------------------------------------------------------------------ backward
 
-// LDS: two images | exchange buffers | per-row arrays | column sums | BatchNorm 2 scale, shift | tile slot
+// LDS: four images | exchange buffers | per-row arrays | column sums | BatchNorm 2 scale, shift | tile slot.  (Four images,
+// so that what several weight-gradient units share -- d(f2) and h over the four FFN chunks, the block input over dWq / dWk /
+// dWv -- is stored once, and two units at a time run behind one barrier.)
 constexpr int kPairXreg = 1024;
-static size_t bwd_pair_lds() { return ((size_t)2 * kPairImg + kPairXFloats + kPairXreg + kTbVecs * 64 + 128 + 64) * sizeof(float); }
+static size_t bwd_pair_lds() { return ((size_t)4 * kPairImg + kPairXFloats + kPairXreg + kTbVecs * 64 + 128 + 64) * sizeof(float); }
 
 template <int W>
 __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
@@ -444,8 +494,10 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* bufA = lds;
     float* bufB = bufA + kPairImg;
-    PairX px{reinterpret_cast<f32x4*>(bufB + kPairImg), 0};
-    float* xreg = bufB + kPairImg + kPairXFloats;   // pooling scores [64]; softmax statistics 3 x [64][4]
+    float* bufC = bufB + kPairImg;
+    float* bufD = bufC + kPairImg;
+    PairX px{reinterpret_cast<f32x4*>(bufD + kPairImg), 0};
+    float* xreg = bufD + kPairImg + kPairXFloats;   // pooling scores [64]; softmax statistics 3 x [64][4]
     float* vacc = xreg + kPairXreg;                 // [kTbVecs][64] column sums of this workgroup
     float* bnv = vacc + kTbVecs * 64;               // [scale | shift] of the second BatchNorm
     int* tile_slot = reinterpret_cast<int*>(bnv + 128);
@@ -458,6 +510,10 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
     float* mine_b = bufB + row * kLdsStride;
     float* lane_a = bufA + 4 * h * kLdsStride + row;       // the lane's place in a transposed image
     float* lane_b = bufB + 4 * h * kLdsStride + row;
+    float* lane_c = bufC + 4 * h * kLdsStride + row;
+    float* lane_d = bufD + 4 * h * kLdsStride + row;
+    float* mine_c = bufC + row * kLdsStride;
+    float* mine_d = bufD + row * kLdsStride;
     const bool row_ok = row < W;
     const int head_off = 16 * (2 * part + h);
     float* pbuf = p.part + (size_t)blockIdx.x * kTbPartStride;
@@ -586,9 +642,16 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
                 x_to_acc(dsum, acc_dh);
             else
                 acc_zero<2>(acc_dh);
-            f32x4 df2o[4], hxo[4];
-            own_groups(df2, part, df2o);
-            own_groups(hx, part, hxo);
+            {
+                // what the chunks' units share, stored once: d(f2) -> image C, h -> image D
+                f32x4 df2o[4], hxo[4];
+                own_groups(df2, part, df2o);
+                own_groups(hx, part, hxo);
+                chain_store_t4(lane_c, part, df2o);
+                chain_store_t4(lane_d, part, hxo);
+                wave_fence();
+                colsum_own(bufC, row0, part, lane, va + kSFb2 * 64);
+            }
 #pragma unroll 1
             for (int c = 0; c < 4; ++c) {
                 f32x4 d1[4];
@@ -618,24 +681,15 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) d1[u] *= g[u];                                     // d(f1_c)
                 }
-                chain_store_t4(lane_b, part, df2o);
-                if (c == 0) {
-                    wave_fence();
-                    colsum_own(bufB, row0, part, lane, va + kSFb2 * 64);
-                }
-                PH_MARK(2)   // feed-forward row products
-                __syncthreads();
-                dw_unit_pair(bufA, bufB, pu + (4 + c) * 4096, first, lane, wave, W);     // dW2[chunk, :] += u_c^T d(f2)
-                PH_MARK(3)   // feed-forward weight gradients
-                chain_store_t4(lane_a, part, hxo);
                 chain_store_t4(lane_b, part, d1);
                 wave_fence();
                 colsum_own(bufB, row0, part, lane, va + (kSFb1 + c) * 64);
                 gemm_groups4<32>(acc_dh, TT + kBtW1T, 8 * c + 4 * part, d1, lane);      // d(h) += d(f1_c) W1[:, my units]^T
-                PH_MARK(2)
+                PH_MARK(2)   // feed-forward row products
                 __syncthreads();
-                dw_unit_pair(bufA, bufB, pu + c * 4096, first, lane, wave, W);           // dW1[:, chunk] += h^T d(f1_c)
-                PH_MARK(3)
+                // dW2[chunk, :] += u_c^T d(f2) and dW1[:, chunk] += h^T d(f1_c)
+                dw_unit_pair2(bufA, bufC, pu + (4 + c) * 4096, bufD, bufB, pu + c * 4096, first, lane, wave, W);
+                PH_MARK(3)   // feed-forward weight gradients
             }
             // ---- LayerNorm 1 backward: d(h) -> dsum = d(x + ao)
             {
@@ -664,12 +718,11 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
                 for (int g = 0; g < 4; ++g) o4[g] = pkeep_load(&AT4O(sv.o, g));
                 dropout_chain(dao, grow, h, seed, p.stream_base + 2 * blk, p.thr, p.scale);
                 own_groups(dao, part, dao4);
-                chain_store_t4(lane_a, part, o4);
-                chain_store_t4(lane_b, part, dao4);
+                // (o -> image C, d(ao) -> image D: their unit runs with dWq's, behind the query pass)
+                chain_store_t4(lane_c, part, o4);
+                chain_store_t4(lane_d, part, dao4);
                 wave_fence();
-                colsum_own(bufB, row0, part, lane, va + kSBo * 64);
-                __syncthreads();
-                dw_unit_pair(bufA, bufB, pu + 8 * 4096, first, lane, wave, W);           // dWo += o^T d(ao)
+                colsum_own(bufD, row0, part, lane, va + kSBo * 64);
                 f32x16 acc[1];
                 acc_zero<1>(acc);
                 gemm_regs<8, 1>(acc, TT + kBtWoT + part * 8 * 64, dao, lane);            // d(o) = d(ao) Wo^T, my tile
@@ -695,13 +748,15 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
             {
                 f32x4 dq[4];
                 {
-                    f32x4 t[4];
+                    f32x4 t[4], t2[4];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) t[g] = pkeep_load(&AT4O(sv.k, g));
+                    for (int g = 0; g < 4; ++g) {
+                        t[g] = pkeep_load(&AT4O(sv.k, g));
+                        t2[g] = pkeep_load(&AT4O(sv.v, g));
+                    }
+                    __syncthreads();   // the other wavefronts have summed their columns of images A / B (LayerNorm 1)
                     chain_store4(mine_a, h, part, t);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) t[g] = pkeep_load(&AT4O(sv.v, g));
-                    chain_store4(mine_b, h, part, t);
+                    chain_store4(mine_b, h, part, t2);
                     float qs[16], doh[16], gh[16];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) t[g] = pkeep_load(&AT4O(sv.q, g));
@@ -731,7 +786,8 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
                 wave_fence();
                 colsum_own(bufB, row0, part, lane, va + kSBq * 64);
                 __syncthreads();
-                dw_unit_pair(bufA, bufB, pu + 9 * 4096, first, lane, wave, W);           // dWq += x^T dq
+                // dWo += o^T d(ao) and dWq += x^T dq; the block input stays in image A for dWk and dWv
+                dw_unit_pair2(bufC, bufD, pu + 8 * 4096, bufA, bufB, pu + 9 * 4096, first, lane, wave, W);
                 gemm_groups4<8>(acc_dx, TT + kBtWqT, 4 * part, dq, lane);
             }
             PH_MARK(7)   // Q / K / V projections backward
@@ -742,8 +798,8 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
                     f32x4 t[4];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) t[g] = pkeep_load(&AT4O(sv.q, g)) * kQScale;
-                    chain_store4(mine_a, h, part, t);
-                    chain_store4(mine_b, h, part, dO);
+                    chain_store4(mine_c, h, part, t);
+                    chain_store4(mine_d, h, part, dO);
                     xreg[64 + row * 4 + 2 * part + h] = st[0];
                     xreg[64 + 256 + row * 4 + 2 * part + h] = st[1];
                     xreg[64 + 512 + row * 4 + 2 * part + h] = D;
@@ -755,37 +811,22 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
                     for (int g = 0; g < 4; ++g) t[g] = pkeep_load(&AT4O(sv.v, g));
                     x4_to_head(t, vh, 1.0f);
                     __syncthreads();   // scaled Q, dO and the statistics of the site are in LDS
-                    attn_bwd_kv<W>(bufA + head_off, bufB + head_off, xreg + 64 + 2 * part + h, 256, kh, vh, gk, gv);
+                    attn_bwd_kv<W>(bufC + head_off, bufD + head_off, xreg + 64 + 2 * part + h, 256, kh, vh, gk, gv);
                     head_to_x4(gk, dk, row_ok ? kLn2 : 0.f);
                     head_to_x4(gv, dv, row_ok ? 1.0f : 0.f);
                 }
                 PH_MARK(8)   // attention backward, key rows
                 __syncthreads();   // Q and dO have been read
                 PH_MARK(10)
-                {
-                    f32x4 xin[4];
-                    if (blk == 0) {
-                        x1_from_conv4(p.cs.a2 + tw * 512, p.cs.s + tw * 512, local_index(ln), bnv, h, part, row_ok, xin);
-                    } else {
-                        const f32x4* tv0 = p.P + kOffTb + kTbVec;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            xin[g] = pkeep_load(&AT4O(p.sv[0].xh2, g)) * tv0[kVLn2G * kVec64 + h * 8 + 4 * part + g] +
-                                     tv0[kVLn2B * kVec64 + h * 8 + 4 * part + g];
-                    }
-                    chain_store_t4(lane_a, part, xin);
-                }
                 chain_store_t4(lane_b, part, dk);
+                chain_store_t4(lane_c, part, dv);
                 wave_fence();
                 colsum_own(bufB, row0, part, lane, va + kSBk * 64);
+                colsum_own(bufC, row0, part, lane, va + kSBv * 64);
                 __syncthreads();
-                dw_unit_pair(bufA, bufB, pu + 10 * 4096, first, lane, wave, W);          // dWk += x^T dk
+                // dWk += x^T dk and dWv += x^T dv
+                dw_unit_pair2(bufA, bufB, pu + 10 * 4096, bufA, bufC, pu + 11 * 4096, first, lane, wave, W);
                 gemm_groups4<8>(acc_dx, TT + kBtWkT, 4 * part, dk, lane);
-                chain_store_t4(lane_b, part, dv);
-                wave_fence();
-                colsum_own(bufB, row0, part, lane, va + kSBv * 64);
-                __syncthreads();
-                dw_unit_pair(bufA, bufB, pu + 11 * 4096, first, lane, wave, W);          // dWv += x^T dv
                 gemm_groups4<8>(acc_dx, TT + kBtWvT, 4 * part, dv, lane);
             }
             acc_to_x<2>(acc_dx, dy);
