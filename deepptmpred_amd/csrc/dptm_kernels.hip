@@ -18,6 +18,7 @@
 #include "dptm_layout.h"
 #include "dptm_attend.h"
 #include "dptm_mfma.h"
+#include "dptm_pair.h"
 #include "dptm_phase.h"
 #include "dptm_kernels.h"
 
@@ -387,6 +388,259 @@ __device__ __forceinline__ void branch_body(const f32x4* __restrict__ P, const u
     }
     PH_MARK(8)   // pooling
     PH_FLUSH
+}
+
+// ------------------------------------------------------------------------------------
+// The same branch for ONE site in FOUR wavefronts (dptm_pair.h): a call of a few dozen sites lasts as long as one
+// wavefront's dependent chain, so two wavefronts share each 32-row block -- every row product is cut by output tile
+// (32 of the 64 output features each; per output feature the same matrix instructions in the same order, so the
+// probabilities are bit-identical to the other tilings'), a lane takes ONE attention head of its row, and the halves of a
+// row vector meet through an LDS exchange wherever the next layer needs the whole row.
+// ------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ void branch_pair_body(const f32x4* __restrict__ P, const uint8_t* __restrict__ tok, int64_t site,
+                                                 float* __restrict__ out, int ldo, int col_off) {
+    static_assert(W <= 64, "a site fills at most two 32-row blocks");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* bufA = lds;
+    float* bufB = bufA + kPairImg;
+    PairX px{reinterpret_cast<f32x4*>(bufB + kPairImg), 0};
+    float* score = bufB + kPairImg + kPairXFloats;  // [64]
+    f32x4* vecs = reinterpret_cast<f32x4*>(score + 64);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pw = wave & 1, part = wave >> 1;
+    const int h = lane >> 5, j = lane & 31;
+    const int row = pw * 32 + j;
+    const bool row_ok = row < W;
+    const bool tap0_ok = row_ok && row > 0, tap2_ok = row_ok && row < W - 1;
+    const int head_off = 16 * (2 * part + h);
+
+    for (int i = tid; i < kVecsF4; i += 256) vecs[i] = P[vecs_source(i)];
+    for (int idx = tid; idx < 64 * 16; idx += 256) {
+        const int r = idx >> 4, c4 = idx & 15;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < W) {
+            int t = tok[site * W + r];
+            t = t > kCodes - 1 ? kCodes - 1 : t;
+            v = P[kOffEmb + t * 16 + c4] + P[kOffPos + r * 16 + c4];
+        }
+        *reinterpret_cast<f32x4*>(bufA + r * kLdsStride + c4 * 4) = v;
+    }
+    __syncthreads();
+
+    f32x4 x1[8];  // residual stream of this lane's row, chain layout (whole row in both wavefronts of a pair)
+    // ---- residual conv block (model.py:129-141), this wavefront's output tile of every convolution
+    {
+        const f32x4* cv = vecs;
+        const f32x4* cvh = vecs + 4 * part;
+        f32x16 acc_s[1], acc_a[1];
+        acc_init_bias<1>(acc_s, cvh + kVScB * kVec64, h, 8);
+        acc_init_bias<1>(acc_a, cvh + kVC3aB * kVec64, h, 8);
+        const float* xc = bufA + row * kLdsStride + 4 * h;
+        const float* xl = tap0_ok ? xc - kLdsStride : xc;
+        const float* xr = tap2_ok ? xc + kLdsStride : xc;
+        const f32x4* wsc = P + kOffScW + part * 8 * 64;
+        const f32x4* wa = P + kOffC3aW + part * 8 * 64;
+        f32x4 a_sc[2], a0[2], a1[2], a2[2], bc[2], bl[2], br[2];  // [parity of u]
+        auto fetch_a = [&](int u, int s) {
+            a_sc[s] = wsc[u * 64 + lane];
+            a0[s] = wa[0 * kMat64 + u * 64 + lane];
+            a1[s] = wa[1 * kMat64 + u * 64 + lane];
+            a2[s] = wa[2 * kMat64 + u * 64 + lane];
+            bc[s] = *reinterpret_cast<const f32x4*>(xc + 8 * u);
+            bl[s] = *reinterpret_cast<const f32x4*>(xl + 8 * u);
+            br[s] = *reinterpret_cast<const f32x4*>(xr + 8 * u);
+        };
+        fetch_a(0, 0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int s = u & 1;
+            if (u + 1 < 8) fetch_a(u + 1, s ^ 1);
+            if (!tap0_ok) bl[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!tap2_ok) br[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mfma(acc_s[0], a_sc[s][e], bc[s][e]);
+                mfma(acc_a[0], a0[s][e], bl[s][e]);
+                mfma(acc_a[0], a1[s][e], bc[s][e]);
+                mfma(acc_a[0], a2[s][e], br[s][e]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // y1 = BN1(swish(conv3a)), own features -> bufB (own rows)
+        f32x4 y[4];
+        acc_to_x<1>(acc_a, y);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 sc = cv[kVBn1S * kVec64 + h * 8 + 4 * part + g], sh = cv[kVBn1T * kVec64 + h * 8 + 4 * part + g];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[g][e] = fmaf(swishf(y[g][e]), sc[e], sh[e]);
+        }
+        chain_store4(bufB + row * kLdsStride, h, part, y);
+        __syncthreads();
+        // conv3b on bufB (all three taps from the image: the row's other half came from the partner)
+        f32x16 acc_b[1];
+        acc_init_bias<1>(acc_b, cvh + kVC3bB * kVec64, h, 8);
+        const float* yc = bufB + row * kLdsStride + 4 * h;
+        const float* yl = tap0_ok ? yc - kLdsStride : yc;
+        const float* yr = tap2_ok ? yc + kLdsStride : yc;
+        const f32x4* wb = P + kOffC3bW + part * 8 * 64;
+        f32x4 c0[2], c1[2], c2[2], dl[2], dc[2], dr[2];
+        auto fetch_b = [&](int u, int s) {
+            c0[s] = wb[0 * kMat64 + u * 64 + lane];
+            c1[s] = wb[1 * kMat64 + u * 64 + lane];
+            c2[s] = wb[2 * kMat64 + u * 64 + lane];
+            dl[s] = *reinterpret_cast<const f32x4*>(yl + 8 * u);
+            dc[s] = *reinterpret_cast<const f32x4*>(yc + 8 * u);
+            dr[s] = *reinterpret_cast<const f32x4*>(yr + 8 * u);
+        };
+        fetch_b(0, 0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int s = u & 1;
+            if (u + 1 < 8) fetch_b(u + 1, s ^ 1);
+            if (!tap0_ok) dl[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!tap2_ok) dr[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mfma(acc_b[0], c0[s][e], dl[s][e]);
+                mfma(acc_b[0], c1[s][e], dc[s][e]);
+                mfma(acc_b[0], c2[s][e], dr[s][e]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 x4[4], s4[4];
+        acc_to_x<1>(acc_b, x4);
+        acc_to_x<1>(acc_s, s4);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 sc = cv[kVBn2S * kVec64 + h * 8 + 4 * part + g], sh = cv[kVBn2T * kVec64 + h * 8 + 4 * part + g];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x4[g][e] = fmaf(swishf(x4[g][e]), sc[e], sh[e]) + s4[g][e];
+        }
+        pair_gather(px, wave, lane, part, x4, x1);
+    }
+
+    // ---- two transformer blocks (model.py:93-118, 172-173)
+#pragma unroll 1
+    for (int blk = 0; blk < 2; ++blk) {
+        const f32x4* T = P + kOffTb + blk * kTbSize;
+        const f32x4* Th = T + part * 8 * 64;           // output tile `part` of a packed 64 x 64 matrix
+        const f32x4* tv = vecs + kVecsConv + blk * kVecsTb;
+        const f32x4* tvh = tv + 4 * part;
+        __syncthreads();   // every wavefront is done reading bufA / bufB (conv taps, or the previous block's K / V)
+        {
+            f32x16 acc[1];
+            f32x4 t[4];
+            acc_init_bias<1>(acc, tvh + kVBk * kVec64, h, 8);
+            gemm_regs<8, 1>(acc, Th + kTbWk, x1, lane);
+            acc_to_x<1>(acc, t);
+            chain_store4(bufA + row * kLdsStride, h, part, t);
+            acc_init_bias<1>(acc, tvh + kVBv * kVec64, h, 8);
+            gemm_regs<8, 1>(acc, Th + kTbWv, x1, lane);
+            acc_to_x<1>(acc, t);
+            chain_store4(bufB + row * kLdsStride, h, part, t);
+        }
+        float q1[1][16];
+        {
+            f32x16 acc[1];
+            f32x4 t[4];
+            acc_init_bias<1>(acc, tvh + kVBq * kVec64, h, 8);
+            gemm_regs<8, 1>(acc, Th + kTbWq, x1, lane);
+            acc_to_x<1>(acc, t);
+            x4_to_head(t, q1[0], kQScale);
+        }
+        __syncthreads();   // K and V of the site are in LDS
+        f32x4 o[8];
+        {
+            float o1[1][16], sm[1], sr[1];   // softmax statistics: not needed for scoring
+            attend<W, 1>(bufA + head_off, bufB + head_off, q1, o1, sm, sr);
+            f32x4 o4[4];
+            head_to_x4(o1[0], o4, 1.0f);
+            pair_gather(px, wave, lane, part, o4, o);
+        }
+        // output projection, residual, LayerNorm 1
+        f32x4 hres[8];
+        {
+            f32x16 acc[1];
+            acc_init_bias<1>(acc, tvh + kVBo * kVec64, h, 8);
+            gemm_regs<8, 1>(acc, Th + kTbWo, o, lane);
+            f32x4 t4[4], r4[4];
+            acc_to_x<1>(acc, t4);
+            own_groups(x1, part, r4);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) t4[g] += r4[g];
+            pair_gather(px, wave, lane, part, t4, hres);
+            layernorm64(hres, tv + kVLn1G * kVec64, tv + kVLn1B * kVec64, h);
+        }
+        // FFN 64 -> 256 (swish) -> 64 in four hidden chunks of 64: first layer by output tile, the chunk's hidden units meet,
+        // second layer by output tile again (so that an output feature sums the chunks in the order of the other tilings)
+        {
+            f32x16 acc_o[1];
+            acc_init_bias<1>(acc_o, tvh + kVB2 * kVec64, h, 8);
+#pragma unroll 1
+            for (int c = 0; c < 4; ++c) {
+                f32x16 acc_h[1];
+                acc_init_bias<1>(acc_h, tv + 9 * kVec64 + 8 * c + 4 * part, h, 32);
+                gemm_regs<8, 1, 2>(acc_h, T + kTbF1 + (2 * c + part) * 8 * 64, hres, lane);
+                f32x4 h4[4], hid[8];
+                acc_to_x<1>(acc_h, h4);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h4[g][e] = swishf(h4[g][e]);
+                pair_gather(px, wave, lane, part, h4, hid);
+                {
+                    const f32x4* w2 = T + kTbF2 + (part * 32 + 8 * c) * 64;
+                    f32x4 a[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) a[u] = w2[u * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) mfma(acc_o[0], a[u][e], hid[u][e]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            f32x4 t4[4], r4[4];
+            acc_to_x<1>(acc_o, t4);
+            own_groups(hres, part, r4);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) t4[g] += r4[g];
+            pair_gather(px, wave, lane, part, t4, x1);
+            layernorm64(x1, tv + kVLn2G * kVec64, tv + kVLn2B * kVec64, h);
+        }
+    }
+
+    // ---- attention pooling (model.py:176-182)
+    {
+        float dotp = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const f32x4 wv = vecs[kVecsPool + h * 8 + u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dotp = fmaf(x1[u][e], wv[e], dotp);
+        }
+        const float ew = __expf(tanhf(xhalf_sum(dotp) + vecs[kVecsPool + kVec64][0]));
+        __syncthreads();  // all attention reads of bufA are finished
+        f32x4 x4[4];
+        own_groups(x1, part, x4);
+        chain_store4(bufA + row * kLdsStride, h, part, x4);
+        if (h == 0 && part == 0) score[row] = ew;
+        __syncthreads();
+        if (tid < 64) {
+            const float* xp = bufA + tid;
+            float den = 0.f, acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < W; ++t) {
+                const float e = score[t];
+                den += e;
+                acc = fmaf(e, xp[t * kLdsStride], acc);
+            }
+            out[site * ldo + col_off + tid] = acc / den;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -819,6 +1073,17 @@ __global__ __launch_bounds__(2 * kSmallTileRows) void front5_kernel(Front5Args p
         if ((int64_t)blockIdx.x * (TR / 21) < p.br.n_sites) branch_body<21, TR>(p.br.P[0], p.br.tok[0], p.br.n_sites, p.br.out, p.br.ldo, 0);
     }
 }
+// The same for calls of at most kPairSites sites: ONE site in four wavefronts, two per 32-row block (branch_pair_body)
+constexpr int64_t kPairSites = 85;      // 3 x 85 = 255 workgroups, one per CU
+__global__ __launch_bounds__(256) void front_pair_kernel(Branch3Args p) {
+    const int64_t site = blockIdx.x;
+    if (blockIdx.y == 0)
+        branch_pair_body<51>(p.P[2], p.tok[2], site, p.out, p.ldo, 2 * kD);
+    else if (blockIdx.y == 1)
+        branch_pair_body<33>(p.P[1], p.tok[1], site, p.out, p.ldo, kD);
+    else
+        branch_pair_body<21>(p.P[0], p.tok[0], site, p.out, p.ldo, 0);
+}
 // the structure layer (grid.y = 0) and the first ESM layer (grid.y = 1) of a small call in one launch
 __global__ __launch_bounds__(512) void dense2_small_kernel(DenseArgs a0, DenseArgs a1) {
     __shared__ float part[8][16][64];
@@ -889,6 +1154,17 @@ hipError_t launch_branch3(const float* const (&params)[3], const uint8_t* const 
     return hipGetLastError();
 }
 
+static constexpr size_t kFrontPairLds = ((size_t)2 * kPairImg + kPairXFloats + 64) * sizeof(float) + kVecsF4 * 16;
+static hipError_t front_pair_attr(int dev) {
+    static bool attr_done_dev[64] = {};
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (attr_done_dev[dev]) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&front_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)kFrontPairLds);
+    if (e == hipSuccess) attr_done_dev[dev] = true;
+    return e;
+}
+
 static constexpr size_t kFrontLds = (2 * kSmallTileRows * kLdsStride + kSmallTileRows) * sizeof(float) + kVecsF4 * 16;
 static_assert(kFrontLds <= 64 * 1024, "the small tile needs no LDS opt-in");
 
@@ -913,6 +1189,18 @@ hipError_t launch_front5(const float* const (&params)[3], const uint8_t* const (
         const char* e = std::getenv("DPTM_SMALL_TILE_SITES");
         return e ? (int64_t)std::atoll(e) : kSmallTileSites;
     }();
+    static const int64_t pair_sites = [] {
+        const char* e = std::getenv("DPTM_SCORE_PAIR_SITES");      // (measurements: 0 switches the four-wavefront sites off)
+        return e ? (int64_t)std::atoll(e) : kPairSites;
+    }();
+    if (n <= pair_sites && n <= kPairSites) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if ((e = front_pair_attr(dev)) != hipSuccess) return e;
+        hipLaunchKernelGGL(front_pair_kernel, dim3((unsigned)n, 3), dim3(256), kFrontPairLds, st, p.br);
+        return hipGetLastError();
+    }
     if (n <= small_tile_sites) {
         // one site per tile for W = 51 and 33 (the most tiles), three for W = 21
         hipLaunchKernelGGL(front5_kernel, dim3((unsigned)n, 3), dim3(2 * kSmallTileRows), kFrontLds, st, p);
@@ -995,6 +1283,7 @@ hipError_t prepare_kernels() {
     if ((e = branch_attr<21>(dev)) != hipSuccess) return e;
     if ((e = branch_attr<33>(dev)) != hipSuccess) return e;
     if ((e = branch_attr<51>(dev)) != hipSuccess) return e;
+    if ((e = front_pair_attr(dev)) != hipSuccess) return e;
     return branch3_attr(dev);
 }
 

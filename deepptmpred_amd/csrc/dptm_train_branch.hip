@@ -26,6 +26,7 @@
 #include "dptm_attend.h"
 #include "dptm_layout.h"
 #include "dptm_mfma.h"
+#include "dptm_pair.h"
 #include "dptm_phase.h"
 #include "dptm_train_device.h"
 #include "dptm_train_kernels.h"

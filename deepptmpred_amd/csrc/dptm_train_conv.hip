@@ -18,6 +18,7 @@
 
 #include "dptm_layout.h"
 #include "dptm_mfma.h"
+#include "dptm_pair.h"
 #include "dptm_train_device.h"
 #include "dptm_train_kernels.h"
 #include "dptm_train_tile.h"
