@@ -47,7 +47,7 @@ def test_golden_fixture(model, golden_dir):
 
 # 53, 192 | 193: the two-wavefront tiles of small calls (one site per workgroup) and their switch to eight-wavefront tiles;
 # 512 | 513: the small-call dense kernels and the throughput ones
-@pytest.mark.parametrize("n", [1, 2, 5, 7, 12, 13, 53, 64, 192, 193, 257, 512, 513, 1000])
+@pytest.mark.parametrize("n", [1, 2, 5, 7, 12, 13, 53, 64, 85, 86, 192, 193, 257, 512, 513, 1000])
 def test_ragged_sizes_vs_oracle(model, weights, n):
     x = spec.synthetic_inputs(n, 1000 + n)
     p = model.predict(x)
@@ -100,12 +100,13 @@ def test_rows_independent_and_ordered(model):
 
 
 def test_small_calls_of_either_tile_agree_bit_for_bit(model):
-    """Calls of up to 512 sites share the dense kernels and differ only in the tile of the sequence branches (two
-    wavefronts up to 192 sites, eight beyond): a site scores the same bits in either, wherever it sits in the call."""
+    """Calls of up to 512 sites share the dense kernels and differ only in the tile of the sequence branches (one site in
+    four wavefronts -- two per 32-row block, every row product cut by output tile -- up to 85 sites, two-wavefront tiles
+    up to 192, eight wavefronts beyond): a site scores the same bits in each, wherever it sits in the call."""
     x = spec.synthetic_inputs(400, 91)
     big = model.predict(x)                              # eight-wavefront tiles
-    for lo, hi in ((0, 150), (37, 229), (399, 400), (208, 400)):
-        small = model.predict([a[lo:hi] for a in x])    # two-wavefront tiles (the 192-site ones at most)
+    for lo, hi in ((0, 150), (37, 229), (399, 400), (208, 400), (100, 185), (7, 93), (311, 364), (0, 21)):
+        small = model.predict([a[lo:hi] for a in x])    # 192 sites at most: two-wavefront tiles; 85 at most: one site per tile
         assert np.array_equal(small, big[lo:hi]), (lo, hi)
     dev = [a for a in x]
     rng = np.random.default_rng(3)
