@@ -462,15 +462,28 @@ y = (np.random.default_rng(2).random(n) < 0.3).astype(np.int64)
 dev = torch.device("cuda:0")
 d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in x]
 lab = torch.from_numpy(y.astype(np.int32)).to(dev)
-tr = _native.Trainer(spec.pack_blob(w), max_batch=64)
+tr = _native.Trainer(spec.pack_blob(w), max_batch=max(64, n))
 o = _native.TrainOpts()
 o.seed = 5
 o.rate_embed, o.rate_conv, o.rate_tb, o.rate_dense = 1e-4, 0.3, 0.1, 0.3
 o.n_global = n; o.n_pos_global = int(y.sum()); o.l2 = 1e-4; o.l2_scale = 1.0
-loss = tr.forward_backward(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), lab.data_ptr(), n, o)
-torch.cuda.synchronize()
+for _ in range({steps}):       # (the same inputs and seed every time: the same masks, the same gradients)
+    loss = tr.forward_backward(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), lab.data_ptr(), n, o)
+    torch.cuda.synchronize()
 np.save({out!r}, np.concatenate([tr.get_grads(), np.float32([loss])]))
 """
+
+
+def _grads_in_a_process(tmp_path, tag, env_extra, n, steps=1):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / f"grads_{tag}.npy")
+    r = subprocess.run([sys.executable, "-c", _TILE_FORM_SCRIPT.format(root=root, n=n, out=out, steps=steps)],
+                       env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return np.load(out)
 
 
 def test_one_site_tiles_with_and_without_shared_row_blocks_agree(tmp_path):
@@ -478,19 +491,20 @@ def test_one_site_tiles_with_and_without_shared_row_blocks_agree(tmp_path):
     output tile or contraction half, a head per lane).  A second process with that form switched off
     (DPTM_TRAIN_PAIR=0: one wavefront per row block, the other two only share the weight-gradient units) must leave
     the same loss and gradients -- dropout on, so the masks of both forms are the same masks."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    got = {}
-    for form in ("1", "0"):
-        out = str(tmp_path / f"grads_pair{form}.npy")
-        env = dict(os.environ, DPTM_TRAIN_PAIR=form)
-        r = subprocess.run([sys.executable, "-c", _TILE_FORM_SCRIPT.format(root=root, n=40, out=out)], env=env, capture_output=True,
-                           text=True, timeout=240)
-        assert r.returncode == 0, r.stderr[-2000:]
-        got[form] = np.load(out)
+    got = {form: _grads_in_a_process(tmp_path, "pair" + form, {"DPTM_TRAIN_PAIR": form}, 40) for form in ("1", "0")}
     a, b = got["1"], got["0"]
     assert a.shape == b.shape and np.isfinite(a).all()
     assert abs(a[-1] - b[-1]) < 1e-6 * max(1.0, abs(b[-1]))                      # loss
     assert np.abs(a[:-1] - b[:-1]).max() < 1e-5 * np.abs(b[:-1]).max()           # every gradient, flat
+
+
+@pytest.mark.parametrize("n", [40, 300])
+def test_graph_replay_of_the_step_equals_eager_issue(tmp_path, n):
+    """DPTM_TRAIN_GRAPH=1 (opt-in): the second call of a configuration records the step's launches -- all streams, the
+    event hand-overs between them -- and the third replays them; the step's scalars then come from a launch of their
+    own in front of the graph.  Loss and gradients of the replayed step equal those of the step issued eagerly."""
+    eager = _grads_in_a_process(tmp_path, f"eager{n}", {"DPTM_TRAIN_GRAPH": "0"}, n, steps=3)
+    graph = _grads_in_a_process(tmp_path, f"graph{n}", {"DPTM_TRAIN_GRAPH": "1"}, n, steps=3)
+    assert eager.shape == graph.shape and np.isfinite(graph).all()
+    assert abs(eager[-1] - graph[-1]) < 1e-6 * max(1.0, abs(eager[-1]))
+    assert np.abs(eager[:-1] - graph[:-1]).max() < 1e-5 * np.abs(eager[:-1]).max()
