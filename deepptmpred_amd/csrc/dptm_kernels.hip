@@ -533,11 +533,11 @@ __device__ __forceinline__ void branch_pair_body(const f32x4* __restrict__ P, co
             f32x16 acc[1];
             f32x4 t[4];
             acc_init_bias<1>(acc, tvh + kVBk * kVec64, h, 8);
-            gemm_regs<8, 1>(acc, Th + kTbWk, x1, lane);
+            gemm_regs<8, 1, 8>(acc, Th + kTbWk, x1, lane);
             acc_to_x<1>(acc, t);
             chain_store4(bufA + row * kLdsStride, h, part, t);
             acc_init_bias<1>(acc, tvh + kVBv * kVec64, h, 8);
-            gemm_regs<8, 1>(acc, Th + kTbWv, x1, lane);
+            gemm_regs<8, 1, 8>(acc, Th + kTbWv, x1, lane);
             acc_to_x<1>(acc, t);
             chain_store4(bufB + row * kLdsStride, h, part, t);
         }
@@ -546,7 +546,7 @@ __device__ __forceinline__ void branch_pair_body(const f32x4* __restrict__ P, co
             f32x16 acc[1];
             f32x4 t[4];
             acc_init_bias<1>(acc, tvh + kVBq * kVec64, h, 8);
-            gemm_regs<8, 1>(acc, Th + kTbWq, x1, lane);
+            gemm_regs<8, 1, 8>(acc, Th + kTbWq, x1, lane);
             acc_to_x<1>(acc, t);
             x4_to_head(t, q1[0], kQScale);
         }
@@ -564,7 +564,7 @@ __device__ __forceinline__ void branch_pair_body(const f32x4* __restrict__ P, co
         {
             f32x16 acc[1];
             acc_init_bias<1>(acc, tvh + kVBo * kVec64, h, 8);
-            gemm_regs<8, 1>(acc, Th + kTbWo, o, lane);
+            gemm_regs<8, 1, 8>(acc, Th + kTbWo, o, lane);
             f32x4 t4[4], r4[4];
             acc_to_x<1>(acc, t4);
             own_groups(x1, part, r4);
@@ -582,7 +582,7 @@ __device__ __forceinline__ void branch_pair_body(const f32x4* __restrict__ P, co
             for (int c = 0; c < 4; ++c) {
                 f32x16 acc_h[1];
                 acc_init_bias<1>(acc_h, tv + 9 * kVec64 + 8 * c + 4 * part, h, 32);
-                gemm_regs<8, 1, 2>(acc_h, T + kTbF1 + (2 * c + part) * 8 * 64, hres, lane);
+                gemm_regs<8, 1, 8>(acc_h, T + kTbF1 + (2 * c + part) * 8 * 64, hres, lane);
                 f32x4 h4[4], hid[8];
                 acc_to_x<1>(acc_h, h4);
 #pragma unroll

@@ -664,7 +664,7 @@ __device__ __forceinline__ void conv_a_fwd_pair_body(const ConvArgs& p) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) x0[u] = *reinterpret_cast<const f32x4*>(xc + 8 * u);
             acc_init_bias<1>(acc, cv + kVScB * kVec64, h, 8);
-            gemm_regs<8, 1>(acc, p.P + kOffScW + part * 8 * 64, x0, lane);
+            gemm_regs<8, 1, 8>(acc, p.P + kOffScW + part * 8 * 64, x0, lane);
             acc_to_x<1>(acc, t);
 #pragma unroll
             for (int g = 0; g < 4; ++g) p.cs.s[co + g * 64] = t[g];
@@ -875,7 +875,7 @@ __device__ __forceinline__ void conv_a_bwd_pair_body(const ConvArgs& p) {
             if (lane < 32) atomicAdd(&vacc[64 + 32 * part + lane], c);
             __syncthreads();
             dw_unit<true>(bufA, bufB, 4, nullptr, pbuf + 3 * 4096, first, lane, wave, W);       // dKsc += x0^T d(x1)
-            gemm_regs<8, 1>(acc, p.PT + kBtScT + part * 8 * 64, d1, lane);
+            gemm_regs<8, 1, 8>(acc, p.PT + kBtScT + part * 8 * 64, d1, lane);
             acc_to_x<1>(acc, dx0);
         }
         dropout4(dx0, tile, h, part, seed, p.stream_embed, p.thr_embed, p.scale_embed);

@@ -263,13 +263,13 @@ __device__ __forceinline__ void tb_fwd_pair_body(const TbFwdArgs& p) {
                 f32x16 acc[1];
                 f32x4 t[4];
                 acc_init_bias<1>(acc, tvh + kVBk * kVec64, h, 8);
-                gemm_regs<8, 1>(acc, Th + kTbWk, x1, lane);
+                gemm_regs<8, 1, 8>(acc, Th + kTbWk, x1, lane);
                 acc_to_x<1>(acc, t);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) pkeep_store(&sv.k[co + g * 64], t[g]);
                 chain_store4(mine_a, h, part, t);
                 acc_init_bias<1>(acc, tvh + kVBv * kVec64, h, 8);
-                gemm_regs<8, 1>(acc, Th + kTbWv, x1, lane);
+                gemm_regs<8, 1, 8>(acc, Th + kTbWv, x1, lane);
                 acc_to_x<1>(acc, t);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) pkeep_store(&sv.v[co + g * 64], t[g]);
@@ -280,7 +280,7 @@ __device__ __forceinline__ void tb_fwd_pair_body(const TbFwdArgs& p) {
                 f32x16 acc[1];
                 f32x4 t[4];
                 acc_init_bias<1>(acc, tvh + kVBq * kVec64, h, 8);
-                gemm_regs<8, 1>(acc, Th + kTbWq, x1, lane);
+                gemm_regs<8, 1, 8>(acc, Th + kTbWq, x1, lane);
                 acc_to_x<1>(acc, t);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) pkeep_store(&sv.q[co + g * 64], t[g]);
@@ -304,7 +304,7 @@ __device__ __forceinline__ void tb_fwd_pair_body(const TbFwdArgs& p) {
             {
                 f32x16 acc[1];
                 acc_init_bias<1>(acc, tvh + kVBo * kVec64, h, 8);
-                gemm_regs<8, 1>(acc, Th + kTbWo, o, lane);
+                gemm_regs<8, 1, 8>(acc, Th + kTbWo, o, lane);
                 f32x4 t4[4], r4[4];
                 acc_to_x<1>(acc, t4);
                 dropout4(t4, grow, h, part, seed, p.stream_base + 2 * blk, p.thr, p.scale);
@@ -571,7 +571,7 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
                     {
                         f32x16 acc_f[1];
                         acc_init_bias<1>(acc_f, tv + 9 * kVec64 + 8 * c + 4 * part, h, 32);
-                        gemm_regs<8, 1, 2>(acc_f, T + kTbF1 + (2 * c + part) * 8 * 64, hx, lane);   // f1_c = h W1[:, my 32 units] + b1
+                        gemm_regs<8, 1, 8>(acc_f, T + kTbF1 + (2 * c + part) * 8 * 64, hx, lane);   // f1_c = h W1[:, my 32 units] + b1
                         f32x4 u_[4];
                         acc_to_x<1>(acc_f, u_);
 #pragma unroll
@@ -587,7 +587,7 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
                     }
                     f32x16 acc_u[1];
                     acc_zero<1>(acc_u);
-                    gemm_regs<8, 1, 2>(acc_u, TT + kBtW2T + (2 * c + part) * 8 * 64, df2, lane);   // d(u_c) = d(f2) W2[my units, :]^T
+                    gemm_regs<8, 1, 8>(acc_u, TT + kBtW2T + (2 * c + part) * 8 * 64, df2, lane);   // d(u_c) = d(f2) W2[my units, :]^T
                     acc_to_x<1>(acc_u, d1);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) d1[u] *= g[u];                                     // d(f1_c)
@@ -636,7 +636,7 @@ __device__ __forceinline__ void tb_bwd_pair_body(const TbBwdArgs& p) {
                 colsum_own(bufD, row0, part, lane, va + kSBo * 64);
                 f32x16 acc[1];
                 acc_zero<1>(acc);
-                gemm_regs<8, 1>(acc, TT + kBtWoT + part * 8 * 64, dao, lane);            // d(o) = d(ao) Wo^T, my tile
+                gemm_regs<8, 1, 8>(acc, TT + kBtWoT + part * 8 * 64, dao, lane);            // d(o) = d(ao) Wo^T, my tile
                 acc_to_x<1>(acc, dO);
                 float s01 = 0.f, s23 = 0.f;
 #pragma unroll
