@@ -935,7 +935,12 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
                  t->use_graph ? nullptr : &sv, st));
     // Small batches without a statistics all-reduce take the per-column kernels of dptm_train_site.hip: one launch per
     // layer and direction instead of a product and half a dozen element-wise passes each.
-    const bool small = B <= kSiteMaxRows && !t->ar_fn &&
+    static const int64_t site_rows = [] {
+        const char* e = std::getenv("DPTM_TRAIN_SITE_ROWS");     // (measurements: another limit, at most kSiteMaxRows)
+        const int64_t v = e ? std::atoll(e) : (int64_t)kSiteFusedRows;
+        return v < kSiteMaxRows ? v : (int64_t)kSiteMaxRows;
+    }();
+    const bool small = B <= site_rows && !t->ar_fn &&
                        ((reinterpret_cast<uintptr_t>(strct) | reinterpret_cast<uintptr_t>(esm)) & 15) == 0;
     // ---------------- forward.  Four lanes of work: the W=21 and W=33 branches on side streams, the W=51 branch (the
     // longest) on the step's main stream `st`, the structure / ESM layers of a small batch on a third side stream `ss`.

@@ -373,7 +373,9 @@ hipError_t t_conv_a_bwd3(const ConvArgs (&a)[3], const ConvGrads (&g)[3], int NW
 hipError_t t_reduce_parts3(const float* const (&part)[3], const int (&nparts)[3], const PartPlan (&plan)[3], hipStream_t st);
 
 // ---- per-site dense layers for small batches (dptm_train_site.hip)
-constexpr int kSiteMaxRows = 128;
+constexpr int kSiteMaxRows = 256;       // what the kernels can take
+constexpr int kSiteFusedRows = 192;     // what a step gives them: a layer is N / 32 workgroups however many rows there are, so
+                                        // beyond this the layer-wise kernels, which spread over the chip, are the faster form
 // inverted dropout on the stateless hash: element (row r, column c) has index r*cols + col0 + c; thr 0: none
 struct SiteDrop {
     unsigned stream, thr;

@@ -39,7 +39,7 @@ __device__ __forceinline__ float drop(float v, const SiteDrop& d, unsigned seed,
 // MFMA step), so that operands that are contiguous along k arrive as 16-byte loads; groups_in_flight() groups are
 // requested before the first product of a batch.  The wavefronts' partial tiles are then summed into the LDS tile
 // [row][column] (every thread of the workgroup must call this: barriers inside; `part` holds 4096 floats).
-template <int RT> constexpr int groups_in_flight() { return RT <= 2 ? 12 : 4; }
+template <int RT> constexpr int groups_in_flight() { return RT <= 2 ? 12 : RT <= 4 ? 4 : 2; }
 
 template <int RT, typename FA, typename FB, typename FM>
 __device__ __forceinline__ void split_k_product(int K, FA colmat, FB rowmat, FM rowmask, float* tile, float* part, int lane, int wave, int nwaves PH_PARAMS) {
@@ -395,8 +395,10 @@ hipError_t t_site_fwd(const SiteFwdArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(site_fwd_kernel<1>, grid, block, 0, st, a);
     else if (rt == 2)
         hipLaunchKernelGGL(site_fwd_kernel<2>, grid, block, 0, st, a);
-    else
+    else if (rt <= 4)
         hipLaunchKernelGGL(site_fwd_kernel<4>, grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL(site_fwd_kernel<8>, grid, block, 0, st, a);
     return hipGetLastError();
 }
 
@@ -409,8 +411,10 @@ hipError_t t_site_bwd(const SiteBwdArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(site_bwd_kernel<1>, grid, block, 0, st, a);
     else if (rt == 2)
         hipLaunchKernelGGL(site_bwd_kernel<2>, grid, block, 0, st, a);
-    else
+    else if (rt <= 4)
         hipLaunchKernelGGL(site_bwd_kernel<4>, grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL(site_bwd_kernel<8>, grid, block, 0, st, a);
     return hipGetLastError();
 }
 
