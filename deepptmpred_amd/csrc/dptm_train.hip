@@ -1420,7 +1420,7 @@ int dptm_trainer_profile_begin(dptm_trainer* t) try {
 }
 
 // Waits for the device and writes the milliseconds of the LAST step's launches (0 for a slot the step did not
-// use: batches of at most 128 sites take other kernels for the per-site layers, never for the branches).
+// use: batches of at most 192 sites take other kernels for the per-site layers, never for the branches).
 int dptm_trainer_profile_end(dptm_trainer* t, float* ms_out) try {
     if (!t || !ms_out) return tfail(DPTM_EINVAL, "dptm_trainer_profile_end: NULL argument");
     if (!t->prof_on) return tfail(DPTM_EINVAL, "dptm_trainer_profile_end: no profile armed");
