@@ -721,16 +721,25 @@ int dptm_trainer_create(const void* weights, size_t nbytes, const dptm_spec* spe
     auto bail = [&](int code, const char* msg) { return tfail(code, msg); };   // `owner` frees the half-built trainer
     if (hipSetDevice(device) != hipSuccess) return bail(DPTM_EINVAL, "dptm_trainer_create: no such device");
     if (pick_streams(t) != hipSuccess) return bail(DPTM_EHIP, "hipStreamCreate failed");
+    // Events that order the trainer's own streams against each other need no system-scope fence (nothing on the host, and
+    // no other device, looks at what they order): DPTM_TRAIN_EVENT_FENCE=1 restores it (A/B)
+    const bool sys_fence = [] {
+        const char* e = std::getenv("DPTM_TRAIN_EVENT_FENCE");
+        return e && e[0] == '1';
+    }();
+    const unsigned own_flags = hipEventDisableTiming | (sys_fence ? 0u : (unsigned)hipEventDisableSystemFence);
     for (int ph = 0; ph < 2; ++ph) {
-        if (hipEventCreateWithFlags(&t->ev_fork[ph], hipEventDisableTiming) != hipSuccess ||
+        if (hipEventCreateWithFlags(&t->ev_fork[ph], own_flags) != hipSuccess ||
             hipEventCreateWithFlags(&t->ev_caller[ph], hipEventDisableTiming) != hipSuccess)
             return bail(DPTM_EHIP, "hipEventCreate failed");
         for (int b = 0; b < 3; ++b)
-            if (hipEventCreateWithFlags(&t->ev_join[ph][b], hipEventDisableTiming) != hipSuccess) return bail(DPTM_EHIP, "hipEventCreate failed");
+            // (the join at the END of the step keeps the fence: behind it the gradients leave for the host or for peers)
+            if (hipEventCreateWithFlags(&t->ev_join[ph][b], ph == 1 ? (unsigned)hipEventDisableTiming : own_flags) != hipSuccess)
+                return bail(DPTM_EHIP, "hipEventCreate failed");
     }
     for (auto& stage : t->ev_sync)
         for (hipEvent_t& e : stage)
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(DPTM_EHIP, "hipEventCreate failed");
+            if (hipEventCreateWithFlags(&e, own_flags) != hipSuccess) return bail(DPTM_EHIP, "hipEventCreate failed");
     const size_t pb = (size_t)t->pm.total * sizeof(float);
     if (hipMalloc((void**)&t->W, pb) != hipSuccess || hipMalloc((void**)&t->G, pb) != hipSuccess ||
         hipMalloc((void**)&t->M, pb) != hipSuccess || hipMalloc((void**)&t->V, pb) != hipSuccess ||
