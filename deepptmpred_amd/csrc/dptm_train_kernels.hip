@@ -564,18 +564,41 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const uint8_t* __restric
 __global__ __launch_bounds__(256) void colsum2_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                       int64_t rows, int cols, int64_t ld, float* __restrict__ stats,
                                                       int rows_per_block) {
-    // with y == nullptr: sums of x and x*x; otherwise sums of x and x*y
+    // with y == nullptr: sums of x and x*x; otherwise sums of x and x*y.  grid.x covers the columns (64 per block)
+    __shared__ float red[2][4][64];
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     const int64_t r1 = min(rows, r0 + rows_per_block);
-    for (int c = blockIdx.x * 64 + (threadIdx.x & 63); c < cols; c += gridDim.x * 64) {
-        float s1 = 0.f, s2 = 0.f;
-        for (int64_t r = r0 + (threadIdx.x >> 6); r < r1; r += 4) {
+    const int l = threadIdx.x & 63, q4 = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + l;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < cols) {
+        int64_t r = r0 + q4;
+        for (; r + 12 < r1; r += 16) {          // four rows' loads in flight
+            float v[4], w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[q] = x[(r + 4 * q) * ld + c];
+                w[q] = y ? y[(r + 4 * q) * ld + c] : v[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s1 += v[q];
+                s2 += v[q] * w[q];
+            }
+        }
+        for (; r < r1; r += 4) {
             const float v = x[r * ld + c];
             s1 += v;
             s2 += v * (y ? y[r * ld + c] : v);
         }
-        atomicAdd(stats + c, s1);
-        atomicAdd(stats + cols + c, s2);
+    }
+    // the block's four wavefronts meet in LDS: a quarter of the atomics on the same addresses (they serialise there)
+    red[0][q4][l] = s1;
+    red[1][q4][l] = s2;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int k = threadIdx.x >> 6;
+        if (c < cols) atomicAdd(stats + k * cols + c, (red[k][0][l] + red[k][1][l]) + (red[k][2][l] + red[k][3][l]));
     }
 }
 
@@ -656,18 +679,40 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ y, int64_t rows, int cols,
                                                             const float* __restrict__ mean_inv, float* __restrict__ sums,
                                                             int rows_per_block) {
+    __shared__ float red[2][4][64];
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     const int64_t r1 = min(rows, r0 + rows_per_block);
-    for (int c = blockIdx.x * 64 + (threadIdx.x & 63); c < cols; c += gridDim.x * 64) {
+    const int l = threadIdx.x & 63, q4 = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + l;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < cols) {
         const float mu = mean_inv[c], inv = mean_inv[cols + c];
-        float s1 = 0.f, s2 = 0.f;
-        for (int64_t r = r0 + (threadIdx.x >> 6); r < r1; r += 4) {
+        int64_t r = r0 + q4;
+        for (; r + 12 < r1; r += 16) {          // four rows' loads in flight
+            float g[4], v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                g[q] = dz[(r + 4 * q) * lddz + dz_col_off + c];
+                v[q] = y[(r + 4 * q) * cols + c];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s1 += g[q];
+                s2 += g[q] * (v[q] - mu) * inv;
+            }
+        }
+        for (; r < r1; r += 4) {
             const float g = dz[r * lddz + dz_col_off + c];
             s1 += g;
             s2 += g * (y[r * cols + c] - mu) * inv;
         }
-        atomicAdd(sums + c, s1);
-        atomicAdd(sums + cols + c, s2);
+    }
+    red[0][q4][l] = s1;
+    red[1][q4][l] = s2;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int k = threadIdx.x >> 6;
+        if (c < cols) atomicAdd(sums + k * cols + c, (red[k][0][l] + red[k][1][l]) + (red[k][2][l] + red[k][3][l]));
     }
 }
 
@@ -1229,7 +1274,7 @@ hipError_t t_embed_bwd(const uint8_t* tok, const float* dx, float* dE, float* dP
     return hipGetLastError();
 }
 static inline int rows_per_block_for(int64_t rows) {
-    int64_t r = (rows + 255) / 256;
+    int64_t r = (rows + 63) / 64;
     if (r < 64) r = 64;
     return (int)r;
 }
