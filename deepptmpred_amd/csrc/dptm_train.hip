@@ -978,8 +978,8 @@ static int enqueue_forward_backward(dptm_trainer* t, const uint8_t* tok21, const
         const char* e = std::getenv("DPTM_TRAIN_MERGE_WGS");    // (measurements: another limit)
         return e ? std::atoll(e) : (int64_t)232;                // a little short of the 256 CUs: the per-site lane needs some too
     }();
-    // (one-site tiles: up to the whole chip -- 85 sites: 0.58 ms in one launch against 0.72 on three streams)
-    merged3 = merged3 && wgs3 <= (one_site_tiles && !std::getenv("DPTM_TRAIN_MERGE_WGS") ? 256 : merge_wgs);
+    // (one-site tiles: wherever they are used, up to 112 sites -- 85 sites: 0.58 ms in one launch against 0.72 on three streams)
+    merged3 = merged3 && wgs3 <= (one_site_tiles && !std::getenv("DPTM_TRAIN_MERGE_WGS") ? 336 : merge_wgs);
     hipStream_t bstream[3] = {t->serial || merged3 ? st : t->aux[0], t->serial || merged3 ? st : t->aux[1], st};
     hipStream_t ss = !t->serial ? t->aux[2] : st;      // per-site layers that run next to the branches
     hipStream_t side[3] = {bstream[0], bstream[1], ss};

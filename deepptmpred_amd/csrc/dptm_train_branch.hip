@@ -145,7 +145,10 @@ int64_t tiles_of(const Cand& c, int64_t n) { return (n + c.S - 1) / c.S; }
 int64_t workgroups_all(int i, int64_t n) { return tiles_of(kCand21[i], n) + tiles_of(kCand33[i], n) + tiles_of(kCand51[i], n); }
 // one round: every workgroup of the three branches finds a CU at once.  The four-wavefront tiles stop a little
 // short of the chip (measured: at 255 sites = 256 workgroups they are already 5 % behind the eight-wavefront tiles).
-bool one_round(int i, int64_t n) { return workgroups_all(i, n) <= (i == 2 ? kCUs : kCUs - 24); }
+// One-site tiles go a little beyond one round (112 sites = 336 workgroups): with two wavefronts per row block their chain
+// is half that of the four-wavefront tiles, and the shortest branch's workgroups fill in behind the longest's (measured
+// per step: 86 sites 0.58 against 0.64 ms, 100 sites 0.62 against 0.64, 128 sites 0.67 against 0.65).
+bool one_round(int i, int64_t n) { return workgroups_all(i, n) <= (i == 2 ? 336 : kCUs - 24); }
 
 // DPTM_TRAIN_TILE=i pins candidate i (measurements: tools/tile_sweep.sh; tests of a tile shape on a small batch)
 int forced_tile() {

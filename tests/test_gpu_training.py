@@ -78,10 +78,10 @@ def test_gradients_match_autograd(rates, n):
 
 
 # batch sizes on both sides of every switch the step makes: 1 row tile / 2 / 4 of the per-site kernels (32|33, 64|65),
-# one-site four-wavefront tiles / whole sites in four wavefronts (85|86), four / eight row tiles of the per-site kernels
+# one round of one-site tiles / more (85|86), one-site four-wavefront tiles / whole sites in four wavefronts (112|113), four / eight row tiles of the per-site kernels
 # (129), per-site kernels / layer-wise products (192|193),
 # four- / eight-wavefront tiles (231|232), the three branches' launches as one / on three streams (540|541); 7 sites: a batch far below one row tile (with 2 sites BatchNorm over two rows amplifies fp32 rounding beyond the bound)
-@pytest.mark.parametrize("n", [7, 33, 65, 85, 86, 129, 192, 193, 231, 232, 540, 541])
+@pytest.mark.parametrize("n", [7, 33, 65, 85, 86, 112, 113, 129, 192, 193, 231, 232, 540, 541])
 def test_gradients_at_regime_boundaries(n):
     import torch
     rates = (1e-4, 0.3, 0.1, 0.3)
