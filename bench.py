@@ -381,7 +381,7 @@ def measure_train(R: Ranks, batch: int, steps: int, warmup: int) -> dict:
             traffic, traffic_file = rec.get("traffic_bytes_per_launch"), os.path.relpath(path, ROOT)
             launches = rec.get("launches_per_pass")
             break
-    kernel_name = ("tb_bwd_pair_kernel<51>" if batch <= 85 else "tb_bwd_kernel<51,256,0>" if batch <= 231
+    kernel_name = ("tb_bwd_pair_kernel<51>" if batch <= 112 else "tb_bwd_kernel<51,256,0>" if batch <= 231
                    else "tb_bwd_kernel<51,512,*> (+ tb_row_bwd_kernel where the backward pass is five launches)")
     roofline = {"bound": "mfma", "kernel": kernel_name, "achieved": bwd_tf,
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": bwd_tf / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,

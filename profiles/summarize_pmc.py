@@ -132,7 +132,7 @@ if os.path.exists(tb) and bench_line("trace_bench.json"):
 
 # ---------------------------------------------------------------- training step
 # The backward pass of the W=51 branch's TransformerBlocks + pooling is ONE launch at small batches
-# (tb_bwd_pair_kernel<51> up to 85 sites, tb_bwd_kernel<51, 256, 0> above) and FIVE at large ones: tb_bwd_kernel<51, 512, 1> (pooling), then per block
+# (tb_bwd_pair_kernel<51> up to 112 sites, tb_bwd_kernel<51, 256, 0> above) and FIVE at large ones: tb_bwd_kernel<51, 512, 1> (pooling), then per block
 # tb_row_bwd_kernel (row-wise half; one kernel for all window sizes -- the W=51 launches are the longest third of its
 # launches) and tb_bwd_kernel<51, 512, 2> (attention half).  Counters and durations are summed over those launches:
 # "per launch" below means per backward pass of the branch.
