@@ -20,6 +20,7 @@
 #include "dptm_mfma.h"
 #include "dptm_pair.h"
 #include "dptm_phase.h"
+#include "dptm_stage.h"
 #include "dptm_kernels.h"
 
 namespace dptm {
@@ -67,18 +68,16 @@ __device__ __forceinline__ void branch_body(const f32x4* __restrict__ P, const u
     const int rows_valid = sites_here * W;
 
     PH_DECL
-    for (int i = tid; i < kVecsF4; i += NT) vecs[i] = P[vecs_source(i)];
-    // ---- embedding + position embedding -> bufA   (model.py:157-158)
-    for (int idx = tid; idx < TR * 16; idx += NT) {
-        const int r = idx >> 4, c4 = idx & 15;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < rows_valid) {
-            const int s = r / W, p = r - s * W;
-            int t = tok[(site0 + s) * W + p];
-            t = t > kCodes - 1 ? kCodes - 1 : t;
-            v = P[kOffEmb + t * 16 + c4] + P[kOffPos + p * 16 + c4];
-        }
-        *reinterpret_cast<f32x4*>(bufA + r * kLdsStride + c4 * 4) = v;
+    // ---- vectors -> LDS, embedding + position embedding -> bufA (model.py:157-158); the thread's loads of both
+    // copies are requested before the first store (dptm_stage.h)
+    {
+        VecsStage<f32x4, NT> vst;
+        EmbedStage<f32x4, W, TR, NT> est;
+        vst.load(P, tid);
+        est.load_tokens(tok + site0 * W, rows_valid, tid);
+        est.load_rows(P, rows_valid, tid);
+        vst.store(vecs, tid);
+        est.store(bufA, rows_valid, tid);
     }
     __syncthreads();
 
@@ -415,16 +414,14 @@ __device__ __forceinline__ void branch_pair_body(const f32x4* __restrict__ P, co
     const bool tap0_ok = row_ok && row > 0, tap2_ok = row_ok && row < W - 1;
     const int head_off = 16 * (2 * part + h);
 
-    for (int i = tid; i < kVecsF4; i += 256) vecs[i] = P[vecs_source(i)];
-    for (int idx = tid; idx < 64 * 16; idx += 256) {
-        const int r = idx >> 4, c4 = idx & 15;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < W) {
-            int t = tok[site * W + r];
-            t = t > kCodes - 1 ? kCodes - 1 : t;
-            v = P[kOffEmb + t * 16 + c4] + P[kOffPos + r * 16 + c4];
-        }
-        *reinterpret_cast<f32x4*>(bufA + r * kLdsStride + c4 * 4) = v;
+    {   // vectors and the site's embedded rows -> LDS, all of a thread's loads requested before its first store
+        VecsStage<f32x4, 256> vst;
+        EmbedStage<f32x4, W, 64, 256> est;
+        vst.load(P, tid);
+        est.load_tokens(tok + site * W, W, tid);
+        est.load_rows(P, W, tid);
+        vst.store(vecs, tid);
+        est.store(bufA, W, tid);
     }
     __syncthreads();
 

@@ -17,6 +17,7 @@
 #include "dptm_kernels.h"
 #include "dptm_layout.h"
 #include "dptm_phase.h"
+#include "dptm_stage.h"
 
 namespace dptm {
 
@@ -245,7 +246,11 @@ __device__ __forceinline__ void branch_h_body(const f32x4* __restrict__ P, const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31;
     PH_DECL
-    for (int i = tid; i < kVecsF4; i += 512) vecs[i] = P[vecs_source(i)];
+    // vectors and both embedding tables -> LDS: the thread's loads (and its token) are requested before the first store
+    VecsStage<f32x4, 512> vst;
+    CopyStage<f32x4, (kCodes + W) * 16, 512> tst;
+    vst.load(P, tid);
+    tst.load(P + kOffEmb, tid);                                                      // kOffPos == kOffEmb + 21*16
     if (tid < (S + 1) * 2) {
         typename HP<MODE>::frag f;
 #pragma unroll
@@ -299,9 +304,10 @@ __device__ __forceinline__ void branch_h_body(const f32x4* __restrict__ P, const
     // Both tables (21 + W rows of 64 floats) are first copied into the still unused second LDS region: a
     // per-lane gather from memory touches up to 64 cache lines per instruction and dominated the prologue.
     f32x4* tabs = reinterpret_cast<f32x4*>(regB);
-    for (int i = tid; i < (kCodes + W) * 16; i += 512) tabs[i] = P[kOffEmb + i];     // kOffPos == kOffEmb + 21*16
     static_assert(kOffPos == kOffEmb + kCodes * 16, "embedding and position tables must be adjacent");
-    int tk = row_ok ? tok[site0 * W + row] : 0;
+    int tk = tok[site0 * W + (row_ok ? row : 0)];
+    vst.store(vecs, tid);
+    tst.store(tabs, tid);
     tk = tk > kCodes - 1 ? kCodes - 1 : tk;
     __syncthreads();
     f32x4 x1[8];
