@@ -198,6 +198,10 @@ __device__ __forceinline__ void branch_body(const f32x4* __restrict__ P, const u
 
     PH_MARK(0)    // conv block
     // ---- two transformer blocks (model.py:93-118, 172-173)
+    // Every product's first two groups of weight fragments are requested while the product before it multiplies
+    // (WHead); the K projection's leave before the barrier in front of it.
+    WHead<2> hk;
+    hk.load(P + kOffTb + kTbWk, 8, 0, lane);
 #pragma unroll 1
     for (int blk = 0; blk < 2; ++blk) {
         const f32x4* T = P + kOffTb + blk * kTbSize;
@@ -205,10 +209,13 @@ __device__ __forceinline__ void branch_body(const f32x4* __restrict__ P, const u
         // every wave is done reading bufA/bufB (conv taps, or the previous block's K/V)
         __syncthreads();
         PH_MARK(2)   // barrier wait
+        WHead<2> hq, ho;
         {
+            WHead<2> hv;
+            hv.load(T + kTbWv, 8, 0, lane);
             f32x16 acc[2];
             acc_init_bias<2>(acc, tv + kVBk * kVec64, h, 8);
-            gemm_regs<8, 2>(acc, T + kTbWk, x1, lane);
+            gemm_regs_head<8, 2>(acc, T + kTbWk, x1, lane, hk);
             float* kb = bufA + row * kLdsStride + 4 * h;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -216,8 +223,9 @@ __device__ __forceinline__ void branch_body(const f32x4* __restrict__ P, const u
                 for (int g = 0; g < 4; ++g)
                     *reinterpret_cast<f32x4*>(kb + 8 * (4 * t + g)) =
                         f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+            hq.load(T + kTbWq, 8, 0, lane);
             acc_init_bias<2>(acc, tv + kVBv * kVec64, h, 8);
-            gemm_regs<8, 2>(acc, T + kTbWv, x1, lane);
+            gemm_regs_head<8, 2>(acc, T + kTbWv, x1, lane, hv);
             float* vb = bufB + row * kLdsStride + 4 * h;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -231,8 +239,9 @@ __device__ __forceinline__ void branch_body(const f32x4* __restrict__ P, const u
         float qa[16], qb[16];
         {
             f32x16 acc[2];
+            ho.load(T + kTbWo, 8, 0, lane);          // in flight across the attention
             acc_init_bias<2>(acc, tv + kVBq * kVec64, h, 8);
-            gemm_regs<8, 2>(acc, T + kTbWq, x1, lane);
+            gemm_regs_head<8, 2>(acc, T + kTbWq, x1, lane, hq);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 qa[r] = acc[0][r] * kQScale;
@@ -290,6 +299,7 @@ __device__ __forceinline__ void branch_body(const f32x4* __restrict__ P, const u
         PH_MARK(5)   // attention
         // back to the chain layout, output projection, residual, LayerNorm 1
         f32x4 hres[8];
+        WHead<2> hf;
         {
             f32x4 o[8];
 #pragma unroll
@@ -298,9 +308,10 @@ __device__ __forceinline__ void branch_body(const f32x4* __restrict__ P, const u
                 o[r >> 2][r & 3] = qa[r];
                 o[4 + (r >> 2)][r & 3] = qb[r];
             }
+            hf.load(T + kTbF1, 8, 0, lane);
             f32x16 acc[2];
             acc_init_bias<2>(acc, tv + kVBo * kVec64, h, 8);
-            gemm_regs<8, 2>(acc, T + kTbWo, o, lane);
+            gemm_regs_head<8, 2>(acc, T + kTbWo, o, lane, ho);
             acc_to_x<2>(acc, hres);
 #pragma unroll
             for (int u = 0; u < 8; ++u) hres[u] += x1[u];
@@ -315,8 +326,10 @@ __device__ __forceinline__ void branch_body(const f32x4* __restrict__ P, const u
             for (int c = 0; c < 4; ++c) {
                 f32x16 acc_h[2];
                 // hidden tiles 2c, 2c+1 <-> bias groups 8c..8c+7 of the 256-vector
+                WHead<2> h2;
+                h2.load(T + kTbF2, 32, 8 * c, lane);
                 acc_init_bias<2>(acc_h, tv + 9 * kVec64 + 8 * c, h, 32);
-                gemm_regs<8, 2, 2>(acc_h, T + kTbF1 + (2 * c) * 8 * 64, hres, lane);
+                gemm_regs_head<8, 2, 2>(acc_h, T + kTbF1 + (2 * c) * 8 * 64, hres, lane, hf);
                 f32x4 hid[8];
                 acc_to_x<2>(acc_h, hid);
 #pragma unroll
@@ -325,11 +338,17 @@ __device__ __forceinline__ void branch_body(const f32x4* __restrict__ P, const u
                     for (int e = 0; e < 4; ++e) hid[u][e] = swishf(hid[u][e]);
                 // second layer: K = 256 -> 32 groups per out tile; this quarter is groups 8c..
                 {
+                    // the next product's first fragments: the next chunk's first layer, or the K projection of the
+                    // next block (the same addresses again after the last block: harmless)
+                    if (c + 1 < 4)
+                        hf.load(T + kTbF1 + (2 * (c + 1)) * 8 * 64, 8, 0, lane);
+                    else
+                        hk.load(P + kOffTb + kTbSize + kTbWk, 8, 0, lane);
                     f32x4 a[8][2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) a[u][t] = T[kTbF2 + (t * 32 + 8 * c + u) * 64 + lane];
+                        for (int t = 0; t < 2; ++t) a[u][t] = h2.a[u][t];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         if (u + 2 < 8) {

@@ -90,6 +90,45 @@ __device__ __forceinline__ void gemm_regs(f32x16 (&acc)[NT], const f32x4* __rest
     }
 }
 
+// The first DIST groups of a product's weight fragments, requested while the PREVIOUS product still multiplies: a
+// product that fetches its own first groups starts with one exposed trip to L2.
+template <int NT, int DIST = 2>
+struct WHead {
+    f32x4 a[DIST][NT];
+    // fragments (t*stride + u0 + u) of a packed matrix whose out tiles are `stride` groups apart
+    __device__ __forceinline__ void load(const f32x4* __restrict__ wp, int stride, int u0, int lane) {
+        DPTM_LOCAL_INDEX(lane);
+#pragma unroll
+        for (int u = 0; u < DIST; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a[u][t] = wp[(t * stride + u0 + u) * 64 + lane];
+    }
+};
+
+// gemm_regs with its first DIST groups already requested (hd.load(wp, K8, 0, lane) earlier)
+template <int K8, int NT, int DIST = 2>
+__device__ __forceinline__ void gemm_regs_head(f32x16 (&acc)[NT], const f32x4* __restrict__ wp, const f32x4 (&x)[K8], int lane,
+                                               const WHead<NT, DIST>& hd) {
+    DPTM_LOCAL_INDEX(lane);
+    f32x4 a[K8][NT];
+#pragma unroll
+    for (int u = 0; u < DIST && u < K8; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[u][t] = hd.a[u][t];
+#pragma unroll
+    for (int u = 0; u < K8; ++u) {
+        if (u + DIST < K8) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) a[u + DIST][t] = wp[(t * K8 + u + DIST) * 64 + lane];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) mfma(acc[t], a[u][t][e], x[u][e]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int NT>
 __device__ __forceinline__ void acc_to_x(const f32x16 (&acc)[NT], f32x4 (&x)[4 * NT]) {
 #pragma unroll
